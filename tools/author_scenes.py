@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Re-author the three BASELINE Cornell-box scenes in the reference's scene-JSON schema.
+
+The schema is the one SURVEY.md A.1 documents (reference scene_parser.h:241-595,
+main.cpp:86-104); the numeric content is the one SURVEY.md A.6 lists.  Nothing is read
+from /root/reference: the scenes are 8-9 instances and are restated here as data.
+Run:  python tools/author_scenes.py   (writes scenes/*.json)
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "scenes")
+
+
+def lambertian(mid, rgb):
+    return {"id": mid, "type": "lambertian", "data": {"color": list(rgb)}}
+
+
+def light_mat(rgb):
+    return {"id": "light", "type": "diffuse_light", "data": {"color": list(rgb)}}
+
+
+def ref(pid, **transform):
+    return {"type": "ref", "primitive": {"id": pid}, "transform": transform}
+
+
+def direct(prim, skip=False, **transform):
+    d = {"type": "direct", "primitive": prim, "transform": transform}
+    if skip:
+        d = {"skip": True, **d}
+    return d
+
+
+def walls(short_box):
+    """The five walls + the two boxes; `short_box` is the list of instance(s) standing in
+    the short-box slot (file order matters: it is the BVH input order)."""
+    return [
+        ref("white_wall", translate=[277.5, 0.0, 277.5]),
+        ref("white_wall", rotate=[1.0, 0.0, 0.0], translate=[277.5, 555, 277.5]),
+        ref("white_wall", rotate=[1.5, 0, 0], translate=[277.5, 277.5, 555]),
+        direct({"type": "rect", "material": {"id": "green"}, "size": [555, 555],
+                "align": "yz", "flip": True}, translate=[555, 277.5, 277.5]),
+        direct({"type": "rect", "material": {"id": "red"}, "size": [555, 555],
+                "align": "yz"}, translate=[0, 277.5, 277.5]),
+        *short_box,
+        direct({"type": "box", "material": {"id": "white"}, "size": [165, 330, 165]},
+               translate=[347.5, 165, 377.5], rotate=[0.0, 0.05, 0.0]),
+    ]
+
+
+def rect_light(w, h, at):
+    return direct({"type": "rect", "material": {"id": "light"}, "size": [w, h]}, translate=list(at))
+
+
+SKIPPED_SPHERE = direct({"type": "sphere", "material": {"id": "light"}}, skip=True,
+                        scale=[100.0, 20.0, 100.0], translate=[273, 200, 171])
+
+SHORT_BOX_XF = dict(translate=[212.5, 82.5, 147.5], rotate=[0.0, -0.1, 0.0])
+
+
+def camera(z):
+    return {"look_from": [278.0, 278.0, z], "look_at": [278.0, 278.0, 0.0], "fov": 40.0,
+            "aperture": 0.0, "dist_to_focus": 10.0}
+
+
+BASE_PRIMS = [
+    {"id": "white_wall", "type": "rect", "material": {"id": "white"}, "size": [555, 555]},
+    {"id": "box", "type": "box", "material": {"id": "white"}, "size": [165, 165, 165]},
+]
+
+scenes = {}
+
+scenes["cornell_box"] = {
+    "camera": camera(-750.0),
+    "world": {"color": [0.0, 0.0, 0.0]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.85, 0.05)), lambertian("red", (0.95, 0.05, 0.05)),
+                  lambertian("white", (0.73, 0.73, 0.73)), light_mat((0.6, 0.6, 0.6))],
+    "primitives": BASE_PRIMS,
+    "instances": walls([ref("box", **SHORT_BOX_XF)]) + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
+}
+
+scenes["cornell_box_small_lights"] = {
+    "camera": camera(-750.0),
+    "world": {"color": [0.0, 0.0, 0.0]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.45, 0.15)), lambertian("red", (0.65, 0.05, 0.05)),
+                  lambertian("white", (0.73, 0.73, 0.73)), light_mat((15.0, 15.0, 15.0))],
+    "primitives": BASE_PRIMS,
+    "instances": walls([ref("box", **SHORT_BOX_XF)]) + [rect_light(30, 30, (243, 554.0, 171)),
+                                                          rect_light(30, 30, (303, 554.0, 171)), SKIPPED_SPHERE],
+}
+
+scenes["cornell_box_with_volume"] = {
+    "camera": camera(-700.0),
+    "world": {"color": [0.1, 0.1, 0.1]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.45, 0.15)), lambertian("red", (0.65, 0.05, 0.05)),
+                  lambertian("white", (0.73, 0.73, 0.73)),
+                  # the reference parser has no "isotropic" case, so this entry is ignored there
+                  {"id": "isotropic", "type": "isotropic", "data": {"color": [0.4, 0.4, 0.4], "density": 0.004}},
+                  light_mat((1.0, 1.0, 1.0))],
+    "primitives": [
+        BASE_PRIMS[0],
+        {"id": "box", "type": "box", "size": [165, 165, 165]},
+        {"id": "fog", "type": "volume", "primitive": "box", "density": 0.004, "color": [0.9, 0.9, 0.9]},
+    ],
+    "instances": walls([{"skip": True, **ref("box", **SHORT_BOX_XF)}, ref("fog", **SHORT_BOX_XF)])
+    + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
+}
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for name, sc in scenes.items():
+        with open(os.path.join(OUT, name + ".json"), "w") as f:
+            json.dump(sc, f, indent=1)
+            f.write("\n")
+        print("wrote", name)
