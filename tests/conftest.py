@@ -1,0 +1,35 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def scene_path(name):
+    return os.path.join(ROOT, "scenes", name + ".json")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement (test infrastructure).  Built on first use."""
+    from oracle import pt_oracle
+
+    pt_oracle.build()
+    return pt_oracle

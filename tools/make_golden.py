@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (oracle/_ref/ref_driver, i.e. the
+reference's own headers compiled in place with its own flags, g++ -O3, threads=1).
+
+Runs only in the build container (needs /root/reference to build oracle/_ref).  The outputs
+are data (inputs + expected outputs); no reference source is stored.
+
+  F1  fb_<scene>_<cfg>.npy       linear float framebuffer SUM (row 0 = bottom), + ray count
+  F2  rng_after_static_init.npy  first 4096 random_double() values after static init
+  F3  tables_<scene>.txt         fwd/inv matrices, bboxes, BVH topology, lights, camera (hex floats)
+  F4  samples_<scene>.npy        first 4096 camera samples: u v ray(7) col(3) rays
+  F5  hits_<scene>.npy           world->hit of the first 4096 camera rays: hit t p n inst
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from oracle import pt_oracle as po  # noqa: E402
+from oracle import scene_params as sp  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
+
+# name -> (width, height, samples, kwargs)
+CONFIGS = {
+    "200x200x16": (200, 200, 16, {}),                       # BASELINE config 1
+    "64x64x4": (64, 64, 4, {}),                             # quick set
+    "96x54x8_t32": (96, 54, 8, dict(block_w=32, block_h=32)),  # 16:9, 3x2 tiles, clamped edge tiles
+    "48x48x8_ls1": (48, 48, 8, dict(light_samples=1)),
+    "48x48x8_norr": (48, 48, 8, dict(russian_roulette=False)),
+    "48x48x8_direct": (48, 48, 8, dict(only_direct=True)),
+    "48x48x8_mb3": (48, 48, 8, dict(max_bounces=3, light_samples=2)),
+}
+FULL_ONLY = {"200x200x16"}  # rendered for every scene; the variants only for these:
+VARIANT_SCENES = {"cornell_box", "cornell_box_with_volume"}
+
+
+def main():
+    po.build()
+    assert po.ref_available(), "oracle/_ref/ref_driver missing (needs /root/reference)"
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"generator": "tools/make_golden.py", "reference_build": "g++ -pthread --std=c++14 -O3, threads=1",
+                "framebuffers": [], "samples": [], "hits": [], "tables": []}
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rng.f64")
+        po.ref_run(sp.load_scene_params(os.path.join(ROOT, "scenes", SCENES[0] + ".json")), "rng", ["4096", out], d)
+        np.save(os.path.join(GOLD, "rng_after_static_init.npy"), np.fromfile(out, np.float64))
+        for scene in SCENES:
+            P = sp.load_scene_params(os.path.join(ROOT, "scenes", scene + ".json"))
+            t = os.path.join(d, "tables.txt")
+            po.ref_run(P, "tables", [t, "1920", "1080"], d)
+            with open(t) as f, open(os.path.join(GOLD, f"tables_{scene}.txt"), "w") as g:
+                g.write(f.read())
+            manifest["tables"].append({"scene": scene, "file": f"tables_{scene}.txt", "camera_aspect": [1920, 1080]})
+            for cname, (w, h, spp, kw) in CONFIGS.items():
+                if cname not in FULL_ONLY and cname != "64x64x4" and scene not in VARIANT_SCENES:
+                    continue
+                cfg = po.make_config(w, h, spp, **kw)
+                fb, rays = po.ref_render(P, cfg, d)
+                fn = f"fb_{scene}_{cname}.npy"
+                np.save(os.path.join(GOLD, fn), fb)
+                manifest["framebuffers"].append({"scene": scene, "config": cname, "file": fn, "width": w, "height": h,
+                                                 "samples": spp, "kwargs": kw, "rays": rays})
+                print(scene, cname, rays, flush=True)
+            cfg = po.make_config(200, 200, 16)
+            n = 4096
+            np.save(os.path.join(GOLD, f"samples_{scene}.npy"), po.ref_samples(P, cfg, n, d))
+            np.save(os.path.join(GOLD, f"hits_{scene}.npy"), po.ref_samples(P, cfg, n, d, mode="hits"))
+            manifest["samples"].append({"scene": scene, "file": f"samples_{scene}.npy", "n": n, "config": "200x200x16"})
+            manifest["hits"].append({"scene": scene, "file": f"hits_{scene}.npy", "n": n, "config": "200x200x16"})
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
