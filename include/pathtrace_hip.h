@@ -1,0 +1,200 @@
+/* pathtrace_hip.h -- C ABI of libpathtrace_hip.so: the MI355X (gfx950) wavefront implementation
+ * of the reference's per-pixel NEE path-tracing hot path.
+ *
+ * This is the drop-in boundary.  In the reference the path is entered one camera
+ * sample at a time through  Integrator::color(ray&, int, long*, path*, bool)  (integrator.h:14,
+ * implemented by NEEIterative::color integrator.h:176-339) from  Tiled::compute  (renderer.h:626-691).
+ * One-ray-per-virtual-call is not a viable device boundary, so the boundary is the Renderer
+ * (renderer.h:114-150): a `HipWavefront : Renderer` forwards start_render / sync_progress /
+ * is_done / finalize to the entry points below (see INTEGRATION.md for the reference-side stub).
+ *
+ * Conventions: plain pointers and sizes, caller owns every host buffer, the library owns device
+ * memory.  All functions return 0 on success and a negative value on failure unless noted;
+ * pt_last_error() gives the message for the calling thread.  One pt_ctx per host thread / GPU.
+ * There is NO CPU fallback: without a usable HIP device pt_create fails.
+ */
+#ifndef PATHTRACE_HIP_H
+#define PATHTRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+/* material.h:27-277 */
+enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
+/* primitive.h:27-256, volume.h:7-93 */
+enum { PT_PRIM_RECT = 0, PT_PRIM_BOX = 1, PT_PRIM_SPHERE = 2, PT_PRIM_VOLUME = 3 };
+/* primitive.h:11-16  enum plane_enum { XY, XZ, YZ } */
+enum { PT_PLANE_XY = 0, PT_PLANE_XZ = 1, PT_PLANE_YZ = 2 };
+
+/* ---- flat POD scene: what World / bvh_node / instance / material objects hold at render time ---- */
+
+typedef struct pt_material {   /* material.h: lambertian / metal / diffuse_light / isotropic with constant_texture */
+    int32_t type;
+    float color[3];            /* albedo or emit colour (texture.h:14-31) */
+    float alpha;               /* constant_texture::a */
+    float power;               /* diffuse_light::power (material.h:243) */
+    int32_t two_sided;         /* diffuse_light::two_sided */
+    float fuzz, ior;           /* metal / dielectric (not yet executed on device; see pt_create) */
+} pt_material;
+
+typedef struct pt_primitive {
+    int32_t type;
+    int32_t material;          /* index into materials (rec.mat_ptr) */
+    float rect[5];             /* rect: x0 z0 x1 z1 y in the XZ-canonical frame (primitive.h:120-124) */
+    int32_t plane;             /* rect: plane_enum */
+    int32_t flipped;           /* rect: ctor argument `flipped` (normal = !flipped) */
+    float p0[3], p1[3];        /* box (primitive.h:229-242) */
+    float center[3], radius;   /* sphere */
+    int32_t boundary;          /* volume: index of the boundary primitive (volume.h:10) */
+    float density;             /* volume */
+    int32_t phase_material;    /* volume: index of its isotropic phase function material */
+} pt_primitive;
+
+typedef struct pt_instance {   /* primitive.h:258-348 */
+    int32_t primitive;
+    float fwd[12];             /* transform3::_transform, rows of the 3x4 affine (transform3.h:69) */
+    float inv[12];             /* transform.inverse(), same layout (transform3.h:51-54) */
+    float bbox[6];             /* instance::bbox min xyz, max xyz (primitive.h:272-296) */
+} pt_instance;
+
+typedef struct pt_bvh_node {   /* bvh.h:6-29; nodes in preorder, node 0 = root */
+    float bbox[6];
+    int32_t left, right;       /* >= 0: node index;  < 0: ~instance_index */
+} pt_bvh_node;
+
+typedef struct pt_camera {     /* camera.h:111-117 for one aspect ratio */
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3], w[3];
+    float lens_radius;
+} pt_camera;
+
+typedef struct pt_scene_desc {
+    int32_t n_materials;  const pt_material *materials;
+    int32_t n_primitives; const pt_primitive *primitives;
+    int32_t n_instances;  const pt_instance *instances;   /* in scene-file order (= hit_record::primitive ids) */
+    int32_t n_nodes;      const pt_bvh_node *nodes;
+    int32_t n_lights;     const int32_t *lights;          /* World::lights as instance indices (world.h:39) */
+    pt_camera camera;
+    float background[3];                                  /* World::background, constant colour (world.h:27-30) */
+} pt_scene_desc;
+
+typedef struct pt_config {     /* the Config fields the path reads (config.h:74-96) */
+    int32_t width, height;     /* film */
+    int32_t max_bounces;       /* integrator.h:186 */
+    int32_t light_samples;     /* integrator.h:221 */
+    int32_t russian_roulette;  /* integrator.h:287 */
+    int32_t only_direct_illumination; /* integrator.h:299 */
+    float normal_offset;       /* integrator.h:274 */
+    uint32_t seed;             /* stream RNG seed (the reference has one fixed mt19937 seed) */
+    int32_t device;            /* HIP device ordinal, -1 = current device */
+    int64_t max_paths_in_flight; /* batch size in camera samples, 0 = default (8 Mi) */
+} pt_config;
+
+/* reference counters: rays = World::hit queries (integrator.h:192,247; renderer.h:696-706) */
+typedef struct pt_counters {
+    uint64_t camera_samples;
+    uint64_t rays, extension_rays, extension_hits, shadow_rays;
+    uint64_t term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
+} pt_counters;
+
+/* per-kernel device time of the last completed pt_render_async, from HIP events on the render
+ * stream (only collected when pt_set_profiling(ctx, 1)); launches and milliseconds per kernel */
+#define PT_N_KERNELS 5
+enum { PT_K_GENERATE = 0, PT_K_EXTEND = 1, PT_K_SHADE = 2, PT_K_CONNECT = 3, PT_K_ACCUMULATE = 4 };
+typedef struct pt_kernel_times {
+    uint64_t launches[PT_N_KERNELS];
+    double ms[PT_N_KERNELS];
+    uint64_t units[PT_N_KERNELS];   /* rays (extend, connect) or path records (others) processed */
+} pt_kernel_times;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Copies the flat scene to the device and allocates the wavefront streams.
+ * Replaces: Renderer::Renderer + Tiled::Tiled (renderer.h:121-133, 545-551) as far as the device is concerned.
+ * Returns NULL on failure (no device, unsupported material/primitive, bad indices). */
+pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config);
+void pt_destroy(pt_ctx *ctx);
+
+/* Enqueue the camera samples  [spp_begin, spp_end) x pixels [x0,x1) x [y0,y1)  (j = 0 is the BOTTOM row,
+ * renderer.h:30) and return immediately.  Replaces the body of Tiled::compute (renderer.h:626-691) for one
+ * tile: jitter + camera::get_ray + NEEIterative::color + framebuffer[j][i] += de_nan(col). */
+int pt_render_async(pt_ctx *ctx, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t spp_begin, int32_t spp_end);
+/* Non-blocking progress (Tiled::sync_progress renderer.h:605-620 reads samples_done[]):
+ * returns 1 when everything enqueued so far has finished, 0 if still running, < 0 on error. */
+int pt_poll(pt_ctx *ctx, uint64_t *samples_done, uint64_t *rays_done);
+/* Block until idle (the reference's main loop spins on is_done(), main.cpp:158-163). */
+int pt_wait(pt_ctx *ctx);
+/* Copy the linear float framebuffer SUM (not mean; renderer.h:682) to host: height*width*3 floats,
+ * row 0 = bottom row, i.e. framebuffer[j][i] of renderer.h:141.  Waits for pending work. */
+int pt_read_framebuffer(pt_ctx *ctx, float *rgb_sum);
+int pt_clear_framebuffer(pt_ctx *ctx);
+int pt_get_counters(pt_ctx *ctx, pt_counters *out);   /* totals since pt_create / pt_clear_framebuffer; waits */
+
+/* Interop for multi-GPU reduction: the device address of the framebuffer (float[height*width*4], RGBA with
+ * A unused, same row order) so that a caller can hand it to RCCL / torch.distributed without a host copy,
+ * and an optional caller-owned device buffer to render into instead. */
+void *pt_device_framebuffer(pt_ctx *ctx);
+int pt_set_device_framebuffer(pt_ctx *ctx, void *device_rgba, size_t bytes);
+/* HIP stream the context launches on (hipStream_t as void*); pt_set_stream(ctx, NULL) = own stream */
+void *pt_get_stream(pt_ctx *ctx);
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+
+int pt_set_profiling(pt_ctx *ctx, int enabled);
+int pt_get_kernel_times(pt_ctx *ctx, pt_kernel_times *out);
+/* debug / parity: radiance of every camera sample of the LAST batch rendered (de_nan not applied):
+ * n = (x1-x0)*(y1-y0)*(spp_end-spp_begin) records of 4 floats, sample-major then row-major pixels. */
+int pt_read_last_batch_radiance(pt_ctx *ctx, float *rgba, size_t max_records, size_t *n_records);
+
+const char *pt_last_error(void);
+int pt_abi_version(void);
+int pt_device_count(void);   /* 0 when no HIP device is usable */
+
+/* ---- host front end (C++ inside the library, C ABI outside) -----------------------------------------
+ * The reference's input formats: config.json (config.h:98-131) and the scene JSON
+ * (scene_parser.h:241-595, main.cpp:86-104).  pth_load builds exactly what main() builds before
+ * renderer->start_render(): Config, World (instances, BVH, lights, background) and the camera. */
+typedef struct pth_scene pth_scene;
+
+typedef struct pth_config {     /* every Config / s_film field (config.h:11-96) */
+    int32_t width, height;
+    float exposure, gamma;      /* stored swapped, as config.h:24-25 does */
+    char ppm_output_path[512], png_output_path[512];
+    char traced_paths_output_path[512], traced_paths_2d_output_path[512];
+    char scene_path[512];
+    int32_t should_trace_paths;
+    float avg_number_of_paths;
+    int32_t block_width, block_height;
+    float trace_probability;
+    int32_t render_type;        /* 0 naive, 1 progressive, 2 tiled (config.h:30-44), 3 hip_wavefront (ours) */
+    int32_t only_direct_illumination;
+    int32_t integrator_type;    /* config.h:46-72; 4 = INEEPT */
+    int32_t max_bounces, samples, light_samples;
+    uint32_t threads;
+    float normal_offset;
+    int32_t russian_roulette;
+} pth_config;
+
+/* Parse a config.json text / file.  Missing required keys fail like the reference's .get<>() throws. */
+int pth_config_from_file(const char *path, pth_config *out);
+int pth_config_from_json(const char *json_text, pth_config *out);
+/* Parse a scene JSON file and build the flat scene for the given film size (camera aspect = width/height). */
+pth_scene *pth_scene_from_file(const char *path, int32_t width, int32_t height);
+pth_scene *pth_scene_from_json(const char *json_text, int32_t width, int32_t height);
+const pt_scene_desc *pth_scene_desc(const pth_scene *s);
+void pth_scene_free(pth_scene *s);
+/* NaiveSpiral tile order (queue.h:68-127): writes up to max_tiles rects (x0,y0,x1,y1) and returns the count */
+int pth_spiral_tiles(int32_t width, int32_t height, int32_t block_w, int32_t block_h, int32_t *rects, int32_t max_tiles);
+/* Film output (renderer.h:24-55, helpers.h:146-168, tonemap.h:4-24): P6 PPM of the SUM framebuffer */
+int pth_write_ppm(const char *path, const float *rgb_sum, int32_t width, int32_t height, int32_t samples, float exposure_field);
+/* The whole program of main.cpp:108-168 for render_type "hip_wavefront": config.json in `workdir`. */
+int pth_main(const char *workdir);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHTRACE_HIP_H */

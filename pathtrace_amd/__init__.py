@@ -1,0 +1,319 @@
+"""pathtrace_amd -- MI355X-native implementation of gillett-hernandez/pathtrace's per-pixel NEE
+path-tracing hot path.
+
+The product is `lib/libpathtrace_hip.so` (hand-written HIP kernels for gfx950 + a C++ host front end behind
+the C ABI of include/pathtrace_hip.h).  This module is only the thin ctypes binding the tests and bench.py
+use; it contains no rendering code and no CPU fallback: every render call goes through the C ABI into the
+HIP kernels, and a missing library or device is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpathtrace_hip.so")
+
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = range(5)
+PRIM_RECT, PRIM_BOX, PRIM_SPHERE, PRIM_VOLUME = range(4)
+KERNELS = ("generate", "extend", "shade", "connect", "accumulate")
+
+
+class PathtraceError(RuntimeError):
+    pass
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("alpha", C.c_float), ("power", C.c_float),
+                ("two_sided", C.c_int32), ("fuzz", C.c_float), ("ior", C.c_float)]
+
+
+class Primitive(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("rect", C.c_float * 5), ("plane", C.c_int32),
+                ("flipped", C.c_int32), ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("center", C.c_float * 3),
+                ("radius", C.c_float), ("boundary", C.c_int32), ("density", C.c_float), ("phase_material", C.c_int32)]
+
+
+class Instance(C.Structure):
+    _fields_ = [("primitive", C.c_int32), ("fwd", C.c_float * 12), ("inv", C.c_float * 12), ("bbox", C.c_float * 6)]
+
+
+class BvhNode(C.Structure):
+    _fields_ = [("bbox", C.c_float * 6), ("left", C.c_int32), ("right", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_float * 3) for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w")] + \
+               [("lens_radius", C.c_float)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_materials", C.c_int32), ("materials", C.POINTER(Material)),
+                ("n_primitives", C.c_int32), ("primitives", C.POINTER(Primitive)),
+                ("n_instances", C.c_int32), ("instances", C.POINTER(Instance)),
+                ("n_nodes", C.c_int32), ("nodes", C.POINTER(BvhNode)),
+                ("n_lights", C.c_int32), ("lights", C.POINTER(C.c_int32)),
+                ("camera", Camera), ("background", C.c_float * 3)]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_bounces", C.c_int32), ("light_samples", C.c_int32),
+                ("russian_roulette", C.c_int32), ("only_direct_illumination", C.c_int32), ("normal_offset", C.c_float),
+                ("seed", C.c_uint32), ("device", C.c_int32), ("max_paths_in_flight", C.c_int64)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("camera_samples", "rays", "extension_rays", "extension_hits", "shadow_rays",
+                                          "term_miss", "term_rr", "term_emitter", "term_pdf", "term_bounce_limit")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("launches", C.c_uint64 * 5), ("ms", C.c_double * 5), ("units", C.c_uint64 * 5)]
+
+
+class HostConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("exposure", C.c_float), ("gamma", C.c_float),
+                ("ppm_output_path", C.c_char * 512), ("png_output_path", C.c_char * 512),
+                ("traced_paths_output_path", C.c_char * 512), ("traced_paths_2d_output_path", C.c_char * 512),
+                ("scene_path", C.c_char * 512), ("should_trace_paths", C.c_int32), ("avg_number_of_paths", C.c_float),
+                ("block_width", C.c_int32), ("block_height", C.c_int32), ("trace_probability", C.c_float),
+                ("render_type", C.c_int32), ("only_direct_illumination", C.c_int32), ("integrator_type", C.c_int32),
+                ("max_bounces", C.c_int32), ("samples", C.c_int32), ("light_samples", C.c_int32), ("threads", C.c_uint32),
+                ("normal_offset", C.c_float), ("russian_roulette", C.c_int32)]
+
+
+# every symbol include/pathtrace_hip.h declares
+EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_poll", "pt_wait", "pt_read_framebuffer",
+           "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
+           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
+           "pt_read_last_batch_radiance", "pt_last_error", "pt_abi_version", "pt_device_count",
+           "pth_config_from_file", "pth_config_from_json", "pth_scene_from_file", "pth_scene_from_json",
+           "pth_scene_desc", "pth_scene_free", "pth_spiral_tiles", "pth_write_ppm", "pth_main"]
+
+_lib = None
+
+
+def lib():
+    """Load libpathtrace_hip.so.  Raises if it has not been built (python -m pathtrace_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PathtraceError(f"{LIB_PATH} is missing: build it with `python -m pathtrace_amd.build` "
+                             "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    L.pt_create.restype = vp
+    L.pt_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(Config)]
+    L.pt_destroy.argtypes = [vp]
+    L.pt_destroy.restype = None
+    L.pt_render_async.argtypes = [vp] + [C.c_int32] * 6
+    L.pt_poll.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pt_wait.argtypes = [vp]
+    L.pt_read_framebuffer.argtypes = [vp, fp]
+    L.pt_clear_framebuffer.argtypes = [vp]
+    L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.pt_device_framebuffer.argtypes = [vp]
+    L.pt_device_framebuffer.restype = vp
+    L.pt_set_device_framebuffer.argtypes = [vp, vp, C.c_size_t]
+    L.pt_get_stream.argtypes = [vp]
+    L.pt_get_stream.restype = vp
+    L.pt_set_stream.argtypes = [vp, vp]
+    L.pt_set_profiling.argtypes = [vp, C.c_int]
+    L.pt_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
+    L.pt_read_last_batch_radiance.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_abi_version.restype = C.c_int
+    L.pt_device_count.restype = C.c_int
+    L.pth_config_from_file.argtypes = [C.c_char_p, C.POINTER(HostConfig)]
+    L.pth_config_from_json.argtypes = [C.c_char_p, C.POINTER(HostConfig)]
+    L.pth_scene_from_file.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    L.pth_scene_from_file.restype = vp
+    L.pth_scene_from_json.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    L.pth_scene_from_json.restype = vp
+    L.pth_scene_desc.argtypes = [vp]
+    L.pth_scene_desc.restype = C.POINTER(SceneDesc)
+    L.pth_scene_free.argtypes = [vp]
+    L.pth_scene_free.restype = None
+    L.pth_spiral_tiles.argtypes = [C.c_int32] * 4 + [C.POINTER(C.c_int32), C.c_int32]
+    L.pth_write_ppm.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+    L.pth_main.argtypes = [C.c_char_p]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().pt_last_error() or b"").decode(errors="replace")
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise PathtraceError(f"{what}: {last_error()}")
+    return rc
+
+
+class Scene:
+    """Flat scene built by the C++ host front end from a reference-format scene JSON."""
+
+    def __init__(self, path: str = None, width: int = 0, height: int = 0, text: str = None):
+        if text is not None:
+            self._h = lib().pth_scene_from_json(text.encode(), width, height)
+        else:
+            self._h = lib().pth_scene_from_file(os.fsencode(path), width, height)
+        if not self._h:
+            raise PathtraceError(f"scene load failed: {last_error()}")
+        self.width, self.height = width, height
+
+    @property
+    def desc(self) -> SceneDesc:
+        return lib().pth_scene_desc(self._h).contents
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pth_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # numpy views for tests
+    def instance_tables(self):
+        d = self.desc
+        n = d.n_instances
+        fwd = np.array([list(d.instances[i].fwd) for i in range(n)], np.float32)
+        inv = np.array([list(d.instances[i].inv) for i in range(n)], np.float32)
+        bbox = np.array([list(d.instances[i].bbox) for i in range(n)], np.float32)
+        return fwd, inv, bbox
+
+    def nodes(self):
+        d = self.desc
+        return [(np.array(list(d.nodes[i].bbox), np.float32), d.nodes[i].left, d.nodes[i].right) for i in range(d.n_nodes)]
+
+    def lights(self):
+        d = self.desc
+        return [d.lights[i] for i in range(d.n_lights)]
+
+    def camera(self):
+        c = self.desc.camera
+        out = []
+        for n in ("origin", "lower_left_corner", "horizontal", "vertical", "u", "v", "w"):
+            out += list(getattr(c, n))
+        return np.array(out + [c.lens_radius], np.float32)
+
+
+def load_config(path: str = None, text: str = None) -> HostConfig:
+    hc = HostConfig()
+    if text is not None:
+        _check(lib().pth_config_from_json(text.encode(), C.byref(hc)), "pth_config_from_json")
+    else:
+        _check(lib().pth_config_from_file(os.fsencode(path), C.byref(hc)), "pth_config_from_file")
+    return hc
+
+
+def spiral_tiles(width, height, bw, bh):
+    n = _check(lib().pth_spiral_tiles(width, height, bw, bh, None, 0), "pth_spiral_tiles")
+    buf = (C.c_int32 * (4 * n))()
+    lib().pth_spiral_tiles(width, height, bw, bh, buf, n)
+    return [tuple(buf[4 * i:4 * i + 4]) for i in range(n)]
+
+
+class Renderer:
+    """Device context (pt_ctx) for one scene + config on one GPU."""
+
+    def __init__(self, scene: Scene, max_bounces=10, light_samples=4, russian_roulette=True, only_direct=False,
+                 normal_offset=1e-4, seed=0, device=-1, max_paths_in_flight=0, width=None, height=None):
+        self.scene = scene
+        self.width = width or scene.width
+        self.height = height or scene.height
+        self.cfg = Config(self.width, self.height, max_bounces, light_samples, int(russian_roulette), int(only_direct),
+                          np.float32(normal_offset), seed, device, max_paths_in_flight)
+        self._h = lib().pt_create(C.byref(scene.desc), C.byref(self.cfg))
+        if not self._h:
+            raise PathtraceError(f"pt_create failed: {last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_async(self, spp_begin, spp_end, rect=None):
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.width, self.height)
+        _check(lib().pt_render_async(self._h, x0, y0, x1, y1, spp_begin, spp_end), "pt_render_async")
+
+    def poll(self):
+        s, r = C.c_uint64(), C.c_uint64()
+        done = _check(lib().pt_poll(self._h, C.byref(s), C.byref(r)), "pt_poll")
+        return bool(done), s.value, r.value
+
+    def wait(self):
+        _check(lib().pt_wait(self._h), "pt_wait")
+
+    def framebuffer(self) -> np.ndarray:
+        fb = np.zeros((self.height, self.width, 3), np.float32)
+        _check(lib().pt_read_framebuffer(self._h, fb.ctypes.data_as(C.POINTER(C.c_float))), "pt_read_framebuffer")
+        return fb
+
+    def clear(self):
+        _check(lib().pt_clear_framebuffer(self._h), "pt_clear_framebuffer")
+
+    def counters(self) -> dict:
+        c = Counters()
+        _check(lib().pt_get_counters(self._h, C.byref(c)), "pt_get_counters")
+        return c.as_dict()
+
+    def render(self, samples, rect=None) -> np.ndarray:
+        self.render_async(0, samples, rect)
+        return self.framebuffer()
+
+    def set_profiling(self, on: bool):
+        _check(lib().pt_set_profiling(self._h, int(on)), "pt_set_profiling")
+
+    def kernel_times(self) -> dict:
+        kt = KernelTimes()
+        _check(lib().pt_get_kernel_times(self._h, C.byref(kt)), "pt_get_kernel_times")
+        return {k: {"launches": int(kt.launches[i]), "ms": float(kt.ms[i]), "units": int(kt.units[i])}
+                for i, k in enumerate(KERNELS)}
+
+    def last_batch_radiance(self, n) -> np.ndarray:
+        out = np.zeros((n, 4), np.float32)
+        got = C.c_size_t()
+        _check(lib().pt_read_last_batch_radiance(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n, C.byref(got)),
+               "pt_read_last_batch_radiance")
+        return out[:got.value]
+
+    def device_framebuffer_ptr(self) -> int:
+        return lib().pt_device_framebuffer(self._h)
+
+    def set_device_framebuffer(self, ptr: int, nbytes: int):
+        _check(lib().pt_set_device_framebuffer(self._h, ptr, nbytes), "pt_set_device_framebuffer")
+
+    def stream_ptr(self) -> int:
+        return lib().pt_get_stream(self._h)
+
+    def set_stream(self, ptr):
+        _check(lib().pt_set_stream(self._h, ptr), "pt_set_stream")
+
+
+def write_ppm(path, fb_sum: np.ndarray, samples: int, exposure_field: float = 2.2):
+    fb = np.ascontiguousarray(fb_sum, np.float32)
+    h, w, _ = fb.shape
+    _check(lib().pth_write_ppm(os.fsencode(path), fb.ctypes.data_as(C.POINTER(C.c_float)), w, h, samples,
+                               C.c_float(exposure_field)), "pth_write_ppm")
+
+
+def device_count() -> int:
+    return lib().pt_device_count()

@@ -1,0 +1,51 @@
+"""Build libpathtrace_hip.so (HIP kernels for gfx950 + C-ABI + C++ host front end) in-tree.
+
+    python -m pathtrace_amd.build [--force]
+
+hipcc cross-compiles gfx950 without a GPU.  Flags that matter for parity: -ffp-contract=off (no FMA
+contraction on host or device) and the default correctly-rounded f32 divide/sqrt (no -ffast-math).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libpathtrace_hip.so")
+SOURCES = [
+    os.path.join(CSRC, "device", "pt_kernels.hip"),
+    os.path.join(CSRC, "device", "pt_context.cpp"),
+    os.path.join(CSRC, "host", "pt_host.cpp"),
+]
+HEADERS = [
+    os.path.join(CSRC, "device", "pt_device.h"),
+    os.path.join(CSRC, "host", "json_min.h"),
+    os.path.join(HERE, "..", "include", "pathtrace_hip.h"),
+]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+         "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

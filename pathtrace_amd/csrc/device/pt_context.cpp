@@ -1,0 +1,541 @@
+// C-ABI implementation (include/pathtrace_hip.h): device context, scene upload, batch scheduling.
+// Compiled with hipcc as host code.  No CPU rendering path exists here: every entry point that produces
+// pixels launches the gfx950 kernels in pt_kernels.hip or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/pathtrace_hip.h"
+#include "pt_device.h"
+
+namespace ptd {
+void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
+void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
+void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
+void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s);
+void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
+}  // namespace ptd
+
+using namespace ptd;
+
+static thread_local std::string g_err;
+static void set_err(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+#define HIP_TRY(x)                                                                         \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            set_err("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+extern "C" const char *pt_last_error(void) { return g_err.c_str(); }
+void pth_set_error(const std::string &m) { g_err = m; }   // used by the host front end (pt_host.cpp)
+extern "C" int pt_abi_version(void) { return PT_ABI_VERSION; }
+extern "C" int pt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+struct TimedLaunch { int kind; hipEvent_t a, b; };
+
+struct pt_ctx {
+    int device = 0;
+    pt_config cfg{};
+    DScene S{};
+    DStreams st{};
+    int64_t P = 0;       // path slots
+    int seg_cap = 2048;
+    int n_seg_max = 0;
+    std::vector<void *> allocs;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t done_ev = nullptr;
+    bool fb_external = false;
+    float4 *fb_own = nullptr;
+    DCounters *host_ctr = nullptr;   // pinned mirror, refreshed after every batch
+    DBatch last_batch{};
+    bool have_last = false;
+    // profiling
+    bool profiling = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> ev_pool;
+    pt_kernel_times ktimes{};
+    DCounters ctr_at_profile_start{};
+};
+
+template <typename T>
+static int dev_alloc(pt_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    c->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+template <typename T>
+static int dev_upload(pt_ctx *c, const T **dst, const std::vector<T> &v)
+{
+    T *p = nullptr;
+    if (dev_alloc(c, &p, v.size())) return -1;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = p;
+    return 0;
+}
+
+static uint32_t mix_lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+static DRect make_rect(float x0, float z0, float x1, float z1, float y, int mat, int plane, int flipped)
+{
+    DRect r;
+    r.x0 = x0; r.z0 = z0; r.x1 = x1; r.z1 = z1; r.y = y;
+    r.plane = plane;
+    r.ny = (float)(2 * (!flipped) - 1);   // primitive.h:212 with normal = !flipped (primitive.h:122)
+    r.mat = mat;
+    return r;
+}
+
+// bvh_node tree -> sweep program (pt_device.h).  Returns the stack depth used, or -1.
+static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<DOp> &ops, int &max_depth)
+{
+    if (child < 0) {
+        DOp op{};
+        op.kind = OP_LEAF;
+        op.a = ~child;
+        ops.push_back(op);
+        return 0;
+    }
+    if (child >= sc->n_nodes) return -1;
+    const pt_bvh_node &n = sc->nodes[child];
+    size_t me = ops.size();
+    DOp en{};
+    en.kind = OP_ENTER;
+    memcpy(en.box, n.bbox, sizeof en.box);
+    ops.push_back(en);
+    if (emit_ops(sc, n.left, depth, ops, max_depth)) return -1;
+    DOp pu{};
+    pu.kind = OP_PUSH;
+    pu.slot = depth;
+    ops.push_back(pu);
+    max_depth = std::max(max_depth, depth + 1);
+    if (emit_ops(sc, n.right, depth + 1, ops, max_depth)) return -1;
+    DOp co{};
+    co.kind = OP_COMBINE;
+    co.slot = depth;
+    ops.push_back(co);
+    ops[me].a = (int)ops.size();
+    return 0;
+}
+
+static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
+{
+    if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_materials < 1 || sc->n_nodes < 1) {
+        set_err("pt_create: empty scene");
+        return -1;
+    }
+    std::vector<DMat> mats(sc->n_materials);
+    for (int i = 0; i < sc->n_materials; i++) {
+        const pt_material &m = sc->materials[i];
+        if (m.type == PT_MAT_DIELECTRIC) {
+            set_err("pt_create: material %d is dielectric, which the device path does not implement yet "
+                    "(outside the BASELINE scenes; SURVEY.md 8f-2)", i);
+            return -1;
+        }
+        if (m.type < 0 || m.type > PT_MAT_ISOTROPIC) { set_err("pt_create: bad material type %d", m.type); return -1; }
+        DMat d{};
+        d.type = m.type; d.r = m.color[0]; d.g = m.color[1]; d.b = m.color[2];
+        d.alpha = m.alpha; d.power = m.power; d.two_sided = m.two_sided;
+        mats[i] = d;
+    }
+    std::vector<DPrim> prims(sc->n_primitives);
+    for (int i = 0; i < sc->n_primitives; i++) {
+        const pt_primitive &p = sc->primitives[i];
+        DPrim d{};
+        d.type = p.type; d.mat = p.material;
+        if (p.material < 0 || p.material >= sc->n_materials) { set_err("pt_create: primitive %d: bad material", i); return -1; }
+        switch (p.type) {
+        case PT_PRIM_RECT:
+            d.r[0] = make_rect(p.rect[0], p.rect[1], p.rect[2], p.rect[3], p.rect[4], p.material, p.plane, p.flipped);
+            break;
+        case PT_PRIM_BOX: {   // primitive.h:232-240
+            const float *a = p.p0, *b = p.p1;
+            d.r[0] = make_rect(a[0], a[1], b[0], b[1], a[2], p.material, PT_PLANE_XY, 1);
+            d.r[1] = make_rect(a[0], a[1], b[0], b[1], b[2], p.material, PT_PLANE_XY, 0);
+            d.r[2] = make_rect(a[1], a[2], b[1], b[2], a[0], p.material, PT_PLANE_YZ, 1);
+            d.r[3] = make_rect(a[1], a[2], b[1], b[2], b[0], p.material, PT_PLANE_YZ, 0);
+            d.r[4] = make_rect(a[0], a[2], b[0], b[2], a[1], p.material, PT_PLANE_XZ, 1);
+            d.r[5] = make_rect(a[0], a[2], b[0], b[2], b[1], p.material, PT_PLANE_XZ, 0);
+            break;
+        }
+        case PT_PRIM_SPHERE:
+            d.cx = p.center[0]; d.cy = p.center[1]; d.cz = p.center[2]; d.radius = p.radius;
+            break;
+        case PT_PRIM_VOLUME:
+            if (p.boundary < 0 || p.boundary >= i || sc->primitives[p.boundary].type == PT_PRIM_VOLUME ||
+                p.phase_material < 0 || p.phase_material >= sc->n_materials) {
+                set_err("pt_create: volume primitive %d: bad boundary / phase material", i);
+                return -1;
+            }
+            d.boundary = p.boundary; d.density = p.density; d.phase_mat = p.phase_material;
+            break;
+        default: set_err("pt_create: primitive %d: unsupported type %d", i, p.type); return -1;
+        }
+        prims[i] = d;
+    }
+    std::vector<DInst> insts(sc->n_instances);
+    int nvol = 0;
+    for (int i = 0; i < sc->n_instances; i++) {
+        const pt_instance &p = sc->instances[i];
+        if (p.primitive < 0 || p.primitive >= sc->n_primitives) { set_err("pt_create: instance %d: bad primitive", i); return -1; }
+        DInst d{};
+        memcpy(d.inv, p.inv, sizeof d.inv);
+        memcpy(d.fwd, p.fwd, sizeof d.fwd);
+        d.prim = p.primitive;
+        d.vol_ordinal = (prims[p.primitive].type == PT_PRIM_VOLUME) ? nvol++ : -1;
+        insts[i] = d;
+    }
+    std::vector<int32_t> lights(sc->lights, sc->lights + sc->n_lights);
+    for (int l : lights)
+        if (l < 0 || l >= sc->n_instances) { set_err("pt_create: bad light index %d", l); return -1; }
+    if (c->cfg.light_samples > 0 && lights.empty()) {
+        set_err("pt_create: light_samples > 0 but the scene has no lights (the reference indexes lights[0] "
+                "unconditionally, world.h:31-35)");
+        return -1;
+    }
+    std::vector<DOp> ops;
+    int max_depth = 0;
+    // validate child indices first
+    for (int i = 0; i < sc->n_nodes; i++)
+        for (int ch : {sc->nodes[i].left, sc->nodes[i].right})
+            if ((ch >= 0 && (ch >= sc->n_nodes || ch <= i)) || (ch < 0 && ~ch >= sc->n_instances)) {
+                set_err("pt_create: bvh node %d: bad child %d (nodes must be in preorder)", i, ch);
+                return -1;
+            }
+    if (emit_ops(sc, 0, 0, ops, max_depth)) { set_err("pt_create: malformed BVH"); return -1; }
+    if (max_depth > PT_MAX_STACK) {
+        set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds %d", max_depth, PT_MAX_STACK);
+        return -1;
+    }
+    DScene &S = c->S;
+    if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
+        dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
+        return -1;
+    S.n_insts = (int)insts.size(); S.n_prims = (int)prims.size(); S.n_mats = (int)mats.size();
+    S.n_ops = (int)ops.size(); S.n_lights = (int)lights.size(); S.n_vol = nvol;
+    const pt_camera &cm = sc->camera;
+    memcpy(S.cam.origin, cm.origin, 12); memcpy(S.cam.llc, cm.lower_left_corner, 12);
+    memcpy(S.cam.horizontal, cm.horizontal, 12); memcpy(S.cam.vertical, cm.vertical, 12);
+    memcpy(S.cam.u, cm.u, 12); memcpy(S.cam.v, cm.v, 12);
+    S.cam.lens_radius = cm.lens_radius;
+    memcpy(S.bg, sc->background, 12);
+    S.width = c->cfg.width; S.height = c->cfg.height;
+    S.max_bounces = c->cfg.max_bounces; S.light_samples = c->cfg.light_samples;
+    S.russian_roulette = c->cfg.russian_roulette; S.only_direct = c->cfg.only_direct_illumination;
+    S.normal_offset = c->cfg.normal_offset;
+    S.seed_k0 = mix_lowbias32(c->cfg.seed);
+    S.seed_k1 = mix_lowbias32(c->cfg.seed + 0x632BE5ABu);
+    return 0;
+}
+
+static int alloc_streams(pt_ctx *c)
+{
+    int64_t want = c->cfg.max_paths_in_flight > 0 ? c->cfg.max_paths_in_flight : (int64_t)8 << 20;
+    want = std::max<int64_t>(want, 64);
+    c->seg_cap = 2048;
+    c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
+    c->P = (int64_t)c->n_seg_max * c->seg_cap;
+    const size_t P = (size_t)c->P;
+    const size_t L = (size_t)std::max(c->cfg.light_samples, 1);
+    DStreams &st = c->st;
+    for (int i = 0; i < 2; i++) {
+        if (dev_alloc(c, &st.q[i].r0, P) || dev_alloc(c, &st.q[i].r1, P) || dev_alloc(c, &st.q[i].s0, P) ||
+            dev_alloc(c, &st.q[i].s1, P) || dev_alloc(c, &st.q[i].count, (size_t)c->n_seg_max))
+            return -1;
+    }
+    if (dev_alloc(c, &st.sq.p0, P) || dev_alloc(c, &st.sq.key, P) || dev_alloc(c, &st.sq.d, P * L) ||
+        dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
+        return -1;
+    if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
+    if (dev_alloc(c, &c->fb_own, (size_t)c->cfg.width * c->cfg.height)) return -1;
+    st.fb = c->fb_own;
+    if (dev_alloc(c, &st.counters, 1)) return -1;
+    HIP_TRY(hipMemset(st.fb, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
+    HIP_TRY(hipMemset(st.counters, 0, sizeof(DCounters)));
+    HIP_TRY(hipHostMalloc((void **)&c->host_ctr, sizeof(DCounters)));
+    memset(c->host_ctr, 0, sizeof(DCounters));
+    return 0;
+}
+
+extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config)
+{
+    if (!scene || !config) { set_err("pt_create: null argument"); return nullptr; }
+    if (config->width < 1 || config->height < 1 || config->max_bounces < 0 || config->light_samples < 0) {
+        set_err("pt_create: bad config");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_err("pt_create: no HIP device available (this library has no CPU fallback)");
+        return nullptr;
+    }
+    pt_ctx *c = new pt_ctx();
+    c->cfg = *config;
+    auto fail = [&]() { std::string e = g_err; pt_destroy(c); g_err = e; return (pt_ctx *)nullptr; };
+    if (config->device >= 0) {
+        if (hipSetDevice(config->device) != hipSuccess) { set_err("pt_create: hipSetDevice(%d) failed", config->device); return fail(); }
+    }
+    if (hipGetDevice(&c->device) != hipSuccess) { set_err("pt_create: hipGetDevice failed"); return fail(); }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { set_err("pt_create: stream"); return fail(); }
+    c->stream = c->own_stream;
+    if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) { set_err("pt_create: event"); return fail(); }
+    if (build_scene(c, scene)) return fail();
+    if (alloc_streams(c)) return fail();
+    return c;
+}
+
+extern "C" void pt_destroy(pt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    if (c->host_ctr) (void)hipHostFree(c->host_ctr);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+static hipEvent_t get_event(pt_ctx *c, size_t i)
+{
+    while (c->ev_pool.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[i];
+}
+
+struct Timer {
+    pt_ctx *c; int kind; bool on; hipEvent_t a = nullptr, b = nullptr;
+    Timer(pt_ctx *c_, int kind_) : c(c_), kind(kind_), on(c_->profiling)
+    {
+        if (!on) return;
+        size_t i = c->timed.size() * 2;
+        a = get_event(c, i); b = get_event(c, i + 1);
+        if (!a || !b) { on = false; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Timer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, c->stream);
+        c->timed.push_back({kind, a, b});
+    }
+};
+
+static int run_batch(pt_ctx *c, const DBatch &b)
+{
+    const DScene &S = c->S;
+    const DStreams &st = c->st;
+    { Timer t(c, PT_K_GENERATE); launch_generate(S, st, b, c->stream); }
+    int qi = 0;
+    for (int bounce = 0; bounce < S.max_bounces; bounce++) {
+        { Timer t(c, PT_K_EXTEND); launch_extend(S, st, b, qi, bounce, c->stream); }
+        { Timer t(c, PT_K_SHADE); launch_shade(S, st, b, qi, bounce, c->stream); }
+        if (S.light_samples > 0) { Timer t(c, PT_K_CONNECT); launch_connect(S, st, b, bounce, c->stream); }
+        qi ^= 1;
+    }
+    { Timer t(c, PT_K_ACCUMULATE); launch_accumulate(S, st, b, c->stream); }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->host_ctr, st.counters, sizeof(DCounters), hipMemcpyDeviceToHost, c->stream));
+    c->last_batch = b;
+    c->have_last = true;
+    return 0;
+}
+
+extern "C" int pt_render_async(pt_ctx *c, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t spp_begin, int32_t spp_end)
+{
+    if (!c) { set_err("pt_render_async: null ctx"); return -1; }
+    if (x0 < 0 || y0 < 0 || x1 > c->cfg.width || y1 > c->cfg.height || x0 >= x1 || y0 >= y1 || spp_begin < 0 || spp_end <= spp_begin) {
+        set_err("pt_render_async: bad rect/sample range [%d,%d)x[%d,%d) spp [%d,%d)", x0, x1, y0, y1, spp_begin, spp_end);
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->profiling) { c->timed.clear(); }
+    const int w = x1 - x0;
+    // rows per band so that one sample of a band fits; then as many samples per batch as fit
+    const int64_t rows_fit = std::max<int64_t>(1, c->P / w);
+    if (w > c->P) { set_err("pt_render_async: rect width %d exceeds max_paths_in_flight", w); return -1; }
+    for (int yb = y0; yb < y1;) {
+        const int hb = (int)std::min<int64_t>(rows_fit, y1 - yb);
+        const int64_t npix = (int64_t)w * hb;
+        const int ns_fit = (int)std::max<int64_t>(1, c->P / npix);
+        for (int s = spp_begin; s < spp_end;) {
+            const int ns = std::min(ns_fit, spp_end - s);
+            DBatch b{};
+            b.x0 = x0; b.y0 = yb; b.w = w; b.h = hb; b.s0 = s; b.ns = ns;
+            b.seg_cap = c->seg_cap;
+            b.n_paths = npix * ns;
+            b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
+            if (run_batch(c, b)) return -1;
+            s += ns;
+        }
+        yb += hb;
+    }
+    HIP_TRY(hipEventRecord(c->done_ev, c->stream));
+    return 0;
+}
+
+extern "C" int pt_poll(pt_ctx *c, uint64_t *samples_done, uint64_t *rays_done)
+{
+    if (!c) { set_err("pt_poll: null ctx"); return -1; }
+    hipError_t e = hipEventQuery(c->done_ev);
+    if (samples_done) *samples_done = c->host_ctr->camera_samples;
+    if (rays_done) *rays_done = c->host_ctr->rays;
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    set_err("pt_poll: %s", hipGetErrorString(e));
+    return -1;
+}
+
+static int collect_times(pt_ctx *c)
+{
+    if (!c->profiling || c->timed.empty()) return 0;
+    pt_kernel_times kt{};
+    for (auto &t : c->timed) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+        kt.launches[t.kind]++;
+        kt.ms[t.kind] += ms;
+    }
+    const DCounters &n = *c->host_ctr, &o = c->ctr_at_profile_start;
+    kt.units[PT_K_GENERATE] = n.camera_samples - o.camera_samples;
+    kt.units[PT_K_EXTEND] = n.ext_rays - o.ext_rays;
+    kt.units[PT_K_SHADE] = n.ext_rays - o.ext_rays;
+    kt.units[PT_K_CONNECT] = n.shadow_rays - o.shadow_rays;
+    kt.units[PT_K_ACCUMULATE] = n.camera_samples - o.camera_samples;
+    // accumulate across render calls since pt_set_profiling(1)
+    for (int k = 0; k < PT_N_KERNELS; k++) {
+        c->ktimes.launches[k] += kt.launches[k];
+        c->ktimes.ms[k] += kt.ms[k];
+        c->ktimes.units[k] += kt.units[k];
+    }
+    c->ctr_at_profile_start = n;
+    c->timed.clear();
+    return 0;
+}
+
+extern "C" int pt_wait(pt_ctx *c)
+{
+    if (!c) { set_err("pt_wait: null ctx"); return -1; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return collect_times(c);
+}
+
+extern "C" int pt_read_framebuffer(pt_ctx *c, float *rgb_sum)
+{
+    if (!c || !rgb_sum) { set_err("pt_read_framebuffer: null argument"); return -1; }
+    if (pt_wait(c)) return -1;
+    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    std::vector<float4> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), c->st.fb, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        rgb_sum[3 * i + 0] = tmp[i].x;
+        rgb_sum[3 * i + 1] = tmp[i].y;
+        rgb_sum[3 * i + 2] = tmp[i].z;
+    }
+    return 0;
+}
+
+extern "C" int pt_clear_framebuffer(pt_ctx *c)
+{
+    if (!c) { set_err("pt_clear_framebuffer: null ctx"); return -1; }
+    if (pt_wait(c)) return -1;
+    HIP_TRY(hipMemsetAsync(c->st.fb, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height, c->stream));
+    HIP_TRY(hipMemsetAsync(c->st.counters, 0, sizeof(DCounters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memset(c->host_ctr, 0, sizeof(DCounters));
+    c->ctr_at_profile_start = DCounters{};
+    return 0;
+}
+
+extern "C" int pt_get_counters(pt_ctx *c, pt_counters *out)
+{
+    if (!c || !out) { set_err("pt_get_counters: null argument"); return -1; }
+    if (pt_wait(c)) return -1;
+    const DCounters &d = *c->host_ctr;
+    out->camera_samples = d.camera_samples;
+    out->rays = d.rays; out->extension_rays = d.ext_rays; out->extension_hits = d.ext_hits; out->shadow_rays = d.shadow_rays;
+    out->term_miss = d.term_miss; out->term_rr = d.term_rr; out->term_emitter = d.term_emitter;
+    out->term_pdf = d.term_pdf; out->term_bounce_limit = d.term_bounce_limit;
+    return 0;
+}
+
+extern "C" void *pt_device_framebuffer(pt_ctx *c) { return c ? (void *)c->st.fb : nullptr; }
+extern "C" int pt_set_device_framebuffer(pt_ctx *c, void *device_rgba, size_t bytes)
+{
+    if (!c) { set_err("pt_set_device_framebuffer: null ctx"); return -1; }
+    if (pt_wait(c)) return -1;
+    if (!device_rgba) { c->st.fb = c->fb_own; c->fb_external = false; return 0; }
+    if (bytes < sizeof(float4) * (size_t)c->cfg.width * c->cfg.height) {
+        set_err("pt_set_device_framebuffer: buffer too small (%zu bytes)", bytes);
+        return -1;
+    }
+    c->st.fb = (float4 *)device_rgba;
+    c->fb_external = true;
+    return 0;
+}
+extern "C" void *pt_get_stream(pt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" int pt_set_stream(pt_ctx *c, void *s)
+{
+    if (!c) { set_err("pt_set_stream: null ctx"); return -1; }
+    if (pt_wait(c)) return -1;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
+{
+    if (!c) { set_err("pt_set_profiling: null ctx"); return -1; }
+    if (pt_wait(c)) return -1;
+    c->profiling = enabled != 0;
+    c->ktimes = pt_kernel_times{};
+    c->timed.clear();
+    c->ctr_at_profile_start = *c->host_ctr;
+    return 0;
+}
+extern "C" int pt_get_kernel_times(pt_ctx *c, pt_kernel_times *out)
+{
+    if (!c || !out) { set_err("pt_get_kernel_times: null argument"); return -1; }
+    if (pt_wait(c)) return -1;
+    *out = c->ktimes;
+    return 0;
+}
+extern "C" int pt_read_last_batch_radiance(pt_ctx *c, float *rgba, size_t max_records, size_t *n_records)
+{
+    if (!c || !rgba || !n_records) { set_err("pt_read_last_batch_radiance: null argument"); return -1; }
+    if (pt_wait(c)) return -1;
+    if (!c->have_last) { *n_records = 0; return 0; }
+    size_t n = std::min<size_t>((size_t)c->last_batch.n_paths, max_records);
+    HIP_TRY(hipMemcpy(rgba, c->st.radiance, n * sizeof(float4), hipMemcpyDeviceToHost));
+    *n_records = n;
+    return 0;
+}

@@ -1,0 +1,115 @@
+// Device-side scene tables and wavefront stream descriptors shared by the host code that fills them
+// (pt_context.cpp) and the gfx950 kernels (pt_kernels.hip).  Plain structs; HIP only for float4/uint2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptd {
+
+// ---- scene tables (a few hundred bytes for the Cornell scenes; read with wave-uniform indices during
+// traversal, so the compiler keeps them in SGPRs via s_load; staged to LDS for per-lane lookups) -------
+struct DRect {           // rect (reference primitive.h:120-183) in its XZ-canonical frame
+    float x0, z0, x1, z1, y;
+    int32_t plane;       // plane_enum XY/XZ/YZ
+    float ny;            // 2*normal-1 = +1 / -1 (primitive.h:212)
+    int32_t mat;
+};
+struct DPrim {           // 240 bytes
+    int32_t type, mat;
+    int32_t boundary;    // volume: prim index
+    int32_t phase_mat;   // volume
+    float density;       // volume
+    float cx, cy, cz, radius;  // sphere
+    int32_t pad[3];
+    DRect r[6];          // rect: r[0];  box: the six sides in primitive.h:232-240 order
+};
+struct DInst {           // 112 bytes
+    float inv[12];       // world -> local (transform.inverse())
+    float fwd[12];       // local -> world
+    int32_t prim;
+    int32_t vol_ordinal; // ordinal among volume instances (stream RNG dimension slot), -1 otherwise
+    int32_t pad[2];
+};
+struct DMat {            // 32 bytes
+    int32_t type;
+    float r, g, b;
+    float alpha, power;
+    int32_t two_sided;
+    int32_t pad;
+};
+// Traversal program: the pointer BVH (reference bvh.h:31-69) flattened into a linear op list that every
+// lane of a wave sweeps in lock step.  eval(node) = ENTER box-test (miss: result MISS, jump to `a`) ;
+// eval(left) ; PUSH slot ; eval(right) ; COMBINE slot   -- COMBINE keeps the reference's rule
+// "both hit: left iff left.t < right.t" (bvh.h:40-47), so exact-t ties and NaN t resolve identically.
+enum { OP_ENTER = 0, OP_LEAF = 1, OP_PUSH = 2, OP_COMBINE = 3 };
+struct DOp {             // 48 bytes
+    int32_t kind;
+    int32_t a;           // ENTER: pc to continue at when the box is missed;  LEAF: instance index
+    int32_t slot;        // PUSH / COMBINE: short-stack slot (static per op)
+    int32_t pad;
+    float box[6];        // ENTER: node bbox
+    int32_t pad2[2];
+};
+#define PT_MAX_STACK 8   // short-stack slots per lane held in LDS (tree height <= 8)
+
+struct DCamera {
+    float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius;
+};
+
+struct DScene {
+    const DInst *insts;
+    const DPrim *prims;
+    const DMat *mats;
+    const DOp *ops;
+    const int32_t *lights;
+    int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
+    DCamera cam;
+    float bg[3];
+    // config
+    int32_t width, height;
+    int32_t max_bounces, light_samples, russian_roulette, only_direct;
+    float normal_offset;
+    uint32_t seed_k0, seed_k1;   // mix(seed), mix(seed + 0x632BE5AB): folded into the per-path keys
+};
+
+// ---- wavefront streams in HBM -----------------------------------------------------------------------
+// A batch owns P = n_seg * seg_cap path slots.  Slot s of segment g lives at g*seg_cap + s.  Queues are
+// *segmented*: block g compacts the survivors of segment g to the front of the same segment of the
+// output queue, so compaction needs no global atomics and the layout is deterministic.
+struct DQueue {          // path queue: 64 B per path
+    float4 *r0;          // origin.xyz, bits(slot)
+    float4 *r1;          // direction.xyz, last_bsdf_pdf
+    float4 *s0;          // beta.xyz, bits(k0)
+    float4 *s1;          // attenuation.xyz, bits(k1)
+    int32_t *count;      // [n_seg] live entries per segment
+};
+struct DShadowQueue {    // per surviving hit: 16 B + light_samples * 24 B
+    float4 *p0;          // hit point p.xyz, bits(slot | pending flag)
+    uint2 *key;          // k0, k1 (only read when the scene has volumes)
+    float4 *d;           // [k][P]: light direction.xyz, coef.x
+    float2 *e;           // [k][P]: coef.y, coef.z
+    int32_t *count;      // [n_seg]
+};
+struct DCounters {
+    unsigned long long camera_samples;
+    unsigned long long rays, ext_rays, ext_hits, shadow_rays;
+    unsigned long long term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
+};
+struct DBatch {
+    int32_t x0, y0, w, h;        // pixel rect of the batch
+    int32_t s0, ns;              // first sample index, samples in the batch
+    int32_t n_seg, seg_cap;      // segmentation of the P = n_seg*seg_cap slots
+    int64_t n_paths;             // w*h*ns  (<= P)
+};
+struct DStreams {
+    DQueue q[2];
+    DShadowQueue sq;
+    float2 *hit;                 // [P]: t, bits(id)   id = -1 miss, else instance*8 + face
+    float4 *radiance;            // [P]: per camera sample radiance sum (rgb, unused)
+    float4 *pending;             // [P]: second emitter addition (integrator.h:319), applied by connect
+    float4 *fb;                  // [height*width] rgba framebuffer SUM
+    DCounters *counters;
+};
+
+}  // namespace ptd

@@ -1,0 +1,857 @@
+// gfx950 (MI355X / CDNA4) wavefront kernels for the per-pixel NEE path-tracing hot path.
+//
+//   generate -> [ extend -> shade -> connect ] x max_bounces -> accumulate
+//
+// The arithmetic of every stage follows the reference (file:line cited per function, paths relative to
+// the reference repository) operation by operation: IEEE float/double +,-,*,/ and sqrt only, compiled
+// with -ffp-contract=off and correctly-rounded division, so that a path's radiance is bit-identical to
+// the CPU restatement in stream mode (oracle/pt_oracle.c; the oracle is never linked here).  The two
+// differences from the reference's sequential program are by construction and documented in DESIGN.md:
+// random numbers are hash(pixel, sample, dimension) instead of one global mt19937, and the four
+// transcendental call sites use the short polynomials below instead of glibc's libm.
+//
+// Wave64 design notes:
+//  * Traversal is a lock-step *sweep* of a flattened traversal program (pt_device.h DOp): every lane of a
+//    wave executes the same op, so node boxes, instance matrices and primitive records are wave-uniform
+//    and arrive through scalar loads into SGPRs; lanes that missed an enclosing box are masked off until
+//    the op where that subtree ends.  The per-lane short stack of partial results lives in LDS,
+//    [slot][lane] so that consecutive lanes hit consecutive banks.
+//  * Queues are segmented per workgroup (pt_device.h): compaction = wave ballot + popcount prefix + a
+//    4-entry LDS scan, no global atomics, deterministic order.
+//  * All streams are float4 / float2 planes indexed by queue position: each wave-level load or store is
+//    one fully coalesced 1 KiB / 512 B transaction.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "pt_device.h"
+
+namespace ptd {
+
+#define PT_BLOCK 256
+#define PT_PI_D 3.14159265358979323846
+#define PT_PI_F 3.14159274f
+
+// ------------------------------------------------------------------------------------------------
+// vec3 (reference vec3.h:11-199); same association as the C++ operators
+// ------------------------------------------------------------------------------------------------
+struct v3 { float x, y, z; };
+#define DEVI __device__ __forceinline__
+DEVI v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEVI v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEVI v3 vscale(float t, v3 v) { return V(t * v.x, t * v.y, t * v.z); }
+DEVI v3 vdivf(v3 v, float t) { return V(v.x / t, v.y / t, v.z / t); }
+DEVI v3 vneg(v3 v) { return V(-v.x, -v.y, -v.z); }
+DEVI float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DEVI v3 vcross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEVI float vsqlen(v3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+DEVI float vlen(v3 v) { return sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); }
+DEVI v3 vunit(v3 v) { return vdivf(v, vlen(v)); }
+DEVI bool is_nanf(float x) { return !(x == x); }
+DEVI bool v_is_nan(v3 v) { return is_nanf(v.x) || is_nanf(v.y) || is_nanf(v.z); }
+
+// ------------------------------------------------------------------------------------------------
+// stream RNG + portable math (definition shared with the CPU restatement's stream mode)
+// ------------------------------------------------------------------------------------------------
+DEVI uint32_t mix_lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+DEVI uint32_t stream_u32(uint32_t k0, uint32_t k1, uint32_t dim)
+{
+    uint32_t x = k0 + dim * 0x9E3779B9u;
+    x ^= x >> 17; x *= 0xed5ad4bbU;
+    x ^= k1;
+    x ^= x >> 11; x *= 0xac4c1b51U;
+    x ^= x >> 15; x *= 0x31848babU;
+    x ^= x >> 14;
+    return x;
+}
+DEVI double rnd(uint32_t k0, uint32_t k1, uint32_t dim) { return (double)stream_u32(k0, k1, dim) * (1.0 / 4294967296.0); }
+
+DEVI void ptm_sincos_2pi(float r, float &s, float &c)
+{
+    float t = r * 4.0f;
+    float q = floorf(t + 0.5f);
+    float f = t - q;
+    float a = f * 1.57079637f;
+    float a2 = a * a;
+    float sp = a + a * a2 * (-0.16666667f + a2 * (0.0083333310f + a2 * (-0.00019840874f + a2 * 2.7525562e-06f)));
+    float cp = 1.0f + a2 * (-0.5f + a2 * (0.041666638f + a2 * (-0.0013888378f + a2 * 2.4760495e-05f)));
+    int qi = ((int)q) & 3;
+    if (qi == 0) { s = sp; c = cp; }
+    else if (qi == 1) { s = cp; c = -sp; }
+    else if (qi == 2) { s = -sp; c = -cp; }
+    else { s = -cp; c = sp; }
+}
+DEVI float ptm_cbrtf(float x)
+{
+    if (!(x > 0.0f)) return 0.0f;
+    uint32_t u = __float_as_uint(x);
+    u = u / 3u + 709921077u;
+    float y = __uint_as_float(u);
+#pragma unroll
+    for (int i = 0; i < 3; i++) y = y - (y * y * y - x) / (3.0f * y * y);
+    return y;
+}
+DEVI float ptm_logf(float x)
+{
+    if (!(x > 0.0f)) return -INFINITY;
+    uint32_t u = __float_as_uint(x);
+    int e = 0;
+    if (u < 0x00800000u) { u = __float_as_uint(x * 8388608.0f); e = -23; }
+    e += (int)(u >> 23) - 127;
+    u = (u & 0x007fffffu) | 0x3f800000u;
+    float m = __uint_as_float(u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = 2.0f * s * (1.0f + z * (0.33333334f + z * (0.2f + z * (0.14285715f + z * 0.11111111f))));
+    float fe = (float)e;
+    return fe * 0.693145752f + (fe * 1.42860677e-06f + p);
+}
+
+// stream-mode dimension layout (must match oracle/pt_oracle.c "stream-mode dimension layout")
+#define DIM_JITTER_U 0u
+#define DIM_JITTER_V 1u
+#define DIM_LENS 2u
+#define DIM_BOUNCE0 8u
+DEVI uint32_t dims_per_bounce(const DScene &S) { return (uint32_t)S.n_vol + (uint32_t)S.light_samples * (3u + (uint32_t)S.n_vol) + 4u; }
+
+// ------------------------------------------------------------------------------------------------
+// transform3 application (reference transform3.h:56-68 through Eigen 3.2.10: t + ((a0*b0 + a1*b1) + a2*b2))
+// ------------------------------------------------------------------------------------------------
+DEVI v3 xf_point(const float *m, v3 p)
+{
+    return V(m[3] + ((m[0] * p.x + m[1] * p.y) + m[2] * p.z),
+             m[7] + ((m[4] * p.x + m[5] * p.y) + m[6] * p.z),
+             m[11] + ((m[8] * p.x + m[9] * p.y) + m[10] * p.z));
+}
+DEVI v3 xf_linear(const float *m, v3 v)
+{
+    return V((m[0] * v.x + m[1] * v.y) + m[2] * v.z,
+             (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+             (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+DEVI v3 xf_normal(const float *inv, v3 n)
+{   // normalize((L^-1)^T n), Eigen's norm association x2 + (y2 + z2)   (transform3.h:60-63)
+    float x = (inv[0] * n.x + inv[4] * n.y) + inv[8] * n.z;
+    float y = (inv[1] * n.x + inv[5] * n.y) + inv[9] * n.z;
+    float z = (inv[2] * n.x + inv[6] * n.y) + inv[10] * n.z;
+    float nrm = sqrtf(x * x + (y * y + z * z));
+    return V(x / nrm, y / nrm, z / nrm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// primitives (reference primitive.h, volume.h) -- "t only" versions for traversal; the winner's
+// hit_record is rebuilt afterwards by finalize_hit()
+// ------------------------------------------------------------------------------------------------
+DEVI v3 shuffle(v3 v, int plane)
+{   // primitive.h:104-121
+    if (plane == 0) return V(v.x, v.z, v.y);
+    if (plane == 2) return V(v.y, v.x, v.z);
+    return v;
+}
+DEVI bool rect_hit_t(const DRect &q, v3 A, v3 B, float t0, float t1, float &t_out)
+{   // primitive.h:186-206
+    v3 o = shuffle(A, q.plane);
+    v3 d = shuffle(B, q.plane);
+    float t = (q.y - o.y) / d.y;
+    if (t < t0 || t > t1) return false;
+    float xh = o.x + t * d.x;
+    float zh = o.z + t * d.z;
+    if (xh < q.x0 || xh > q.x1 || zh < q.z0 || zh > q.z1) return false;
+    t_out = t;
+    return true;
+}
+DEVI v3 rect_normal(const DRect &q, v3 B)
+{   // primitive.h:212-222 (two_sided is always true)
+    v3 n = shuffle(V(0.0f, q.ny, 0.0f), q.plane);
+    if (vdot(B, n) > 0) n = vneg(n);
+    return n;
+}
+DEVI bool box_hit_t(const DPrim &p, v3 A, v3 B, float t0, float t1, float &t_out, int &face)
+{   // primitive.h:243-246 -> hittable_list.h:21-38 (closest_so_far shrinks; a later equal t replaces)
+    bool any = false;
+    float closest = t1;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float t;
+        if (rect_hit_t(p.r[i], A, B, t0, closest, t)) {
+            any = true;
+            closest = t;
+            face = i;
+        }
+    }
+    t_out = closest;
+    return any;
+}
+DEVI bool sphere_hit_t(const DPrim &s, v3 A, v3 B, float t_min, float t_max, float &t_out)
+{   // primitive.h:64-95
+    v3 oc = vsub(A, V(s.cx, s.cy, s.cz));
+    float a = vdot(B, B);
+    float b = vdot(oc, B);
+    float c = vdot(oc, oc) - s.radius * s.radius;
+    float disc = b * b - a * c;
+    if (disc > 0) {
+        float temp = (-b - sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) { t_out = temp; return true; }
+        temp = (-b + sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) { t_out = temp; return true; }
+    }
+    return false;
+}
+// rect / box / sphere by (wave-uniform) type
+DEVI bool solid_hit_t(const DPrim &p, v3 A, v3 B, float t0, float t1, float &t_out, int &face)
+{
+    face = 0;
+    if (p.type == 0) return rect_hit_t(p.r[0], A, B, t0, t1, t_out);
+    if (p.type == 1) return box_hit_t(p, A, B, t0, t1, t_out, face);
+    if (p.type == 2) return sphere_hit_t(p, A, B, t0, t1, t_out);
+    return false;
+}
+DEVI bool volume_hit_t(const DScene &S, const DPrim &p, v3 A, v3 B, float t_min, float t_max, uint32_t k0, uint32_t k1,
+                       uint32_t dim, float &t_out)
+{   // volume.h:29-93
+    const DPrim &b = S.prims[p.boundary];
+    float t1v, t2v;
+    int f;
+    if (solid_hit_t(b, A, B, -FLT_MAX, FLT_MAX, t1v, f)) {
+        if (solid_hit_t(b, A, B, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
+            if (t1v < t_min) t1v = t_min;
+            if (t2v > t_max) t2v = t_max;
+            if (t1v >= t2v) return false;
+            if (t1v < 0) t1v = 0;
+            float dlen = vlen(B);
+            float distance_inside = (t2v - t1v) * dlen;
+            float u = (float)rnd(k0, k1, dim);
+            float hit_distance = (-(1 / p.density)) * ptm_logf(u);
+            if (hit_distance < distance_inside) {
+                t_out = t1v + hit_distance / dlen;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep.
+// Returns id = -1 (miss) or instance*8 + face, and t.   `stk` points at this lane's column of the LDS
+// short stack ([slot][PT_BLOCK] float2).
+// ------------------------------------------------------------------------------------------------
+DEVI bool aabb_hit(const float *box, v3 A, v3 inv, float tmin, float tmax)
+{   // aabb.h:34-53 with invD hoisted (same value for every node of one ray)
+    bool ok = true;
+    {
+        float t0 = (box[0] - A.x) * inv.x, t1 = (box[3] - A.x) * inv.x;
+        if (inv.x < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) ok = false;
+    }
+    {
+        float t0 = (box[1] - A.y) * inv.y, t1 = (box[4] - A.y) * inv.y;
+        if (inv.y < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) ok = false;
+    }
+    {
+        float t0 = (box[2] - A.z) * inv.z, t1 = (box[5] - A.z) * inv.z;
+        if (inv.z < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+        if (tmax <= tmin) ok = false;
+    }
+    return ok;
+}
+
+DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, v3 B, uint32_t k0, uint32_t k1, uint32_t vol_dim_base,
+                    float2 *stk, float &out_t, int &out_id)
+{
+    const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
+    v3 inv = V(1.0f / B.x, 1.0f / B.y, 1.0f / B.z);
+    float cur_t = 0.0f;
+    int cur_id = -1;
+    int skip = lane_valid ? 0 : 0x7fffffff;
+    const int n_ops = S.n_ops;
+    for (int pc = 0; pc < n_ops; ++pc) {
+        const DOp &op = S.ops[pc];
+        const bool active = pc >= skip;
+        const int kind = op.kind;
+        if (kind == OP_ENTER) {
+            if (active && !aabb_hit(op.box, A, inv, T_MIN, T_MAX)) { cur_id = -1; skip = op.a; }
+        } else if (kind == OP_LEAF) {
+            const int ii = op.a;
+            const DInst &in = S.insts[ii];
+            const DPrim &pr = S.prims[in.prim];
+            if (active) {
+                v3 Al = xf_point(in.inv, A);        // ray::apply (ray.h:20-24)
+                v3 Bl = xf_linear(in.inv, B);
+                float t;
+                int face = 0;
+                bool hit;
+                if (pr.type == 3) hit = volume_hit_t(S, pr, Al, Bl, T_MIN, T_MAX, k0, k1, vol_dim_base + (uint32_t)in.vol_ordinal, t);
+                else hit = solid_hit_t(pr, Al, Bl, T_MIN, T_MAX, t, face);
+                cur_id = hit ? (ii * 8 + face) : -1;
+                cur_t = hit ? t : 0.0f;
+            }
+        } else if (kind == OP_PUSH) {
+            if (active) stk[op.slot * PT_BLOCK] = make_float2(cur_t, __int_as_float(cur_id));
+        } else {  // OP_COMBINE   (bvh.h:36-66)
+            if (active) {
+                float2 l = stk[op.slot * PT_BLOCK];
+                int lid = __float_as_int(l.y);
+                bool take_left = (lid >= 0) && ((cur_id < 0) || (l.x < cur_t));
+                if (take_left) { cur_t = l.x; cur_id = lid; }
+            }
+        }
+    }
+    out_t = cur_t;
+    out_id = cur_id;
+}
+
+// hit_record of the winning primitive: rec.p, rec.normal, rec.mat_ptr  (primitive.h:186-225, 298-312; volume.h:77-88)
+struct HitInfo { v3 p, n; int mat; };
+DEVI HitInfo finalize_hit(const DScene &S, v3 A, v3 B, float t, int id, bool need_normal)
+{
+    const int ii = id >> 3, face = id & 7;
+    const DInst &in = S.insts[ii];
+    const DPrim &pr = S.prims[in.prim];
+    v3 Al = xf_point(in.inv, A);
+    v3 Bl = xf_linear(in.inv, B);
+    v3 pl = vadd(Al, vscale(t, Bl));   // r.point_at_parameter(t) in local space
+    v3 nl;
+    HitInfo h;
+    if (pr.type == 0) { nl = rect_normal(pr.r[0], Bl); h.mat = pr.r[0].mat; }
+    else if (pr.type == 1) { nl = rect_normal(pr.r[face], Bl); h.mat = pr.r[face].mat; }
+    else if (pr.type == 2) { nl = vdivf(vsub(pl, V(pr.cx, pr.cy, pr.cz)), pr.radius); h.mat = pr.mat; }
+    else { nl = V(1.0f, 0.0f, 0.0f); h.mat = pr.phase_mat; }
+    h.p = xf_point(in.fwd, pl);
+    h.n = need_normal ? xf_normal(in.inv, nl) : V(0.0f, 0.0f, 0.0f);
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights and pdfs (primitive.h:151-175, 319-342; pdf.h; helpers.h:112-144; material.h)
+// ------------------------------------------------------------------------------------------------
+DEVI float prim_pdf_value(const DPrim &p, v3 o, v3 v)
+{
+    if (p.type == 0) {   // rect::pdf_value primitive.h:151-166
+        const DRect &q = p.r[0];
+        float t;
+        if (rect_hit_t(q, o, v, 0.001f, FLT_MAX, t)) {
+            float area = (q.x1 - q.x0) * (q.z1 - q.z0);
+            float vl = vlen(v);
+            float d2 = (t * vl) * (t * vl);
+            float cosine = fabsf(vdot(v, rect_normal(q, v)) / vl);
+            return d2 / (cosine * area);
+        }
+        return 0.0f;
+    }
+    if (p.type == 2) {   // sphere::pdf_value primitive.h:37-51
+        float t;
+        if (sphere_hit_t(p, o, v, 0.001f, FLT_MAX, t)) {
+            float cos_theta_max = sqrtf(1 - p.radius * p.radius / vsqlen(vsub(V(p.cx, p.cy, p.cz), o)));
+            float solid_angle = (float)(2 * PT_PI_D * (double)(1 - cos_theta_max));
+            return 1 / solid_angle;
+        }
+        return 0.0f;
+    }
+    return 0.0f;   // hittable.h:27
+}
+DEVI float instance_pdf_value(const DScene &S, int ii, v3 o, v3 v)
+{   // primitive.h:319-337
+    const DInst &in = S.insts[ii];
+    return prim_pdf_value(S.prims[in.prim], xf_point(in.inv, o), xf_linear(in.inv, v));
+}
+struct Onb { v3 u, v, w; };
+DEVI Onb onb_from_w(v3 n)
+{   // helpers.h:127-136
+    Onb b;
+    b.w = vunit(n);
+    v3 a = (fabsf(b.w.x) > 0.9) ? V(0.0f, 1.0f, 0.0f) : V(1.0f, 0.0f, 0.0f);
+    b.v = vunit(vcross(b.w, a));
+    b.u = vcross(b.w, b.v);
+    return b;
+}
+DEVI v3 onb_local(const Onb &b, v3 a) { return vadd(vadd(vscale(a.x, b.u), vscale(a.y, b.v)), vscale(a.z, b.w)); }
+
+DEVI v3 prim_random(const DPrim &p, v3 o, uint32_t k0, uint32_t k1, uint32_t dim)
+{
+    if (p.type == 0) {   // rect::random primitive.h:168-175 (first draw -> z, second -> x)
+        const DRect &q = p.r[0];
+        double rz = rnd(k0, k1, dim + 0);
+        double rx = rnd(k0, k1, dim + 1);
+        float pz = (float)((double)q.z0 + rz * (double)(q.z1 - q.z0));
+        float px = (float)((double)q.x0 + rx * (double)(q.x1 - q.x0));
+        return vsub(shuffle(V(px, q.y, pz), q.plane), o);
+    }
+    if (p.type == 2) {   // sphere::random primitive.h:52-59 + random.h:45-55
+        v3 direction = vsub(V(p.cx, p.cy, p.cz), o);
+        float d2 = vsqlen(direction);
+        Onb uvw = onb_from_w(direction);
+        float r1 = (float)rnd(k0, k1, dim + 0);
+        float r2 = (float)rnd(k0, k1, dim + 1);
+        float z = 1 + r2 * (sqrtf(1 - p.radius * p.radius / d2) - 1);
+        float s, c;
+        ptm_sincos_2pi(r1, s, c);
+        float x = c * sqrtf(1 - z * z);
+        float y = s * sqrtf(1 - z * z);
+        return onb_local(uvw, V(x, y, z));
+    }
+    return V(1.0f, 0.0f, 0.0f);   // hittable.h:28
+}
+DEVI v3 instance_random(const DScene &S, int ii, v3 o, uint32_t k0, uint32_t k1, uint32_t dim)
+{   // primitive.h:338-342
+    const DInst &in = S.insts[ii];
+    return xf_linear(in.fwd, prim_random(S.prims[in.prim], xf_point(in.inv, o), k0, k1, dim));
+}
+DEVI float power_heuristic(float fPdf, float gPdf)
+{   // helpers.h:138-144, nf = ng = 1, pow = 2
+    float f = 1 * fPdf, g = 1 * gPdf;
+    float fp = f * f;
+    return fp / (fp + g * g);
+}
+DEVI float cosine_pdf_value(v3 normal, v3 direction)
+{   // pdf.h:18-29
+    float cosine = vdot(vunit(direction), vunit(normal));
+    if (cosine > 0) return (float)((double)cosine / PT_PI_D);
+    return 0.0f;
+}
+DEVI float material_value(int type, v3 normal, v3 direction)
+{
+    if (type == 0 || type == 1) return cosine_pdf_value(normal, direction);   // material.h:66-69, 105-108
+    if (type == 4) return (float)(1 / (4 * PT_PI_D));                        // pdf.h:41-44
+    return 0.0f;                                                             // void_pdf
+}
+DEVI v3 random_in_unit_sphere(uint32_t k0, uint32_t k1, uint32_t dim)
+{   // random.h:17-24 with cos(acos(x)) = x
+    float su, cu;
+    ptm_sincos_2pi((float)rnd(k0, k1, dim + 0), su, cu);
+    float cv = (float)(2 * rnd(k0, k1, dim + 1) - 1);
+    float sv2 = 1.0f - cv * cv;
+    float sv = sqrtf(sv2 > 0.0f ? sv2 : 0.0f);
+    float w = ptm_cbrtf((float)rnd(k0, k1, dim + 2));
+    return V(cu * sv * w, cv * w, su * sv * w);
+}
+DEVI v3 material_generate(int type, v3 normal, uint32_t k0, uint32_t k1, uint32_t dim)
+{
+    if (type == 0 || type == 1) {   // cosine_pdf::generate pdf.h:30-33, random.h:36-44
+        Onb uvw = onb_from_w(normal);
+        float r1 = (float)rnd(k0, k1, dim + 0);
+        float r2 = (float)rnd(k0, k1, dim + 1);
+        float z = sqrtf(1 - r2);
+        float s, c;
+        ptm_sincos_2pi(r1, s, c);
+        float x = c * sqrtf(r2);
+        float y = s * sqrtf(r2);
+        return onb_local(uvw, V(x, y, z));
+    }
+    return random_in_unit_sphere(k0, k1, dim);
+}
+DEVI v3 material_emitted(const DMat &m, v3 ray_dir, v3 normal)
+{   // material.h:211-229 (others: material.h:21-24)
+    if (m.type != 3) return V(0.0f, 0.0f, 0.0f);
+    bool aligned = vdot(normal, ray_dir) > 0;
+    if (!aligned || m.two_sided) return vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
+    return V(0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workgroup helpers
+// ------------------------------------------------------------------------------------------------
+// exclusive offset of `pred` lanes within the workgroup and the workgroup total (two barriers)
+DEVI int block_compact(bool pred, int &total, int *sh4)
+{
+    const unsigned long long m = __ballot(pred);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int woff = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sh4[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PT_BLOCK / 64; w++) {
+        int c = sh4[w];
+        if (w < wave) off += c;
+        tot += c;
+    }
+    __syncthreads();
+    total = tot;
+    return off + woff;
+}
+enum { C_SAMPLES = 0, C_RAYS, C_EXT, C_EXT_HITS, C_SHADOW, C_MISS, C_RR, C_EMIT, C_PDF, C_LIMIT, C_N };
+DEVI void flush_counters(unsigned int *sh_ctr, DCounters *g)
+{
+    __syncthreads();
+    if (threadIdx.x < C_N) {
+        unsigned long long v = sh_ctr[threadIdx.x];
+        if (v) atomicAdd(((unsigned long long *)g) + threadIdx.x, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate: renderer.h:648-649 jitter + camera::get_ray camera.h:38-47
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DBatch b)
+{
+    const int seg = blockIdx.x;
+    const long long seg_base = (long long)seg * b.seg_cap;
+    long long remaining = b.n_paths - seg_base;
+    const int n = remaining <= 0 ? 0 : (remaining < b.seg_cap ? (int)remaining : b.seg_cap);
+    const int npix = b.w * b.h;
+    DQueue q = st.q[0];
+    for (int i = threadIdx.x; i < n; i += PT_BLOCK) {
+        const long long slot = seg_base + i;
+        const int s_local = (int)(slot / npix);
+        const int pl = (int)(slot - (long long)s_local * npix);
+        const int py = pl / b.w, px = pl - py * b.w;
+        const int pi = b.x0 + px, pj = b.y0 + py;
+        const uint32_t pixel = (uint32_t)(pj * S.width + pi);
+        const uint32_t sample = (uint32_t)(b.s0 + s_local);
+        const uint32_t k0 = mix_lowbias32(pixel ^ S.seed_k0);
+        const uint32_t k1 = mix_lowbias32(sample ^ S.seed_k1);
+        float u = (float)((double)pi + rnd(k0, k1, DIM_JITTER_U)) / (float)S.width;
+        float v = (float)((double)pj + rnd(k0, k1, DIM_JITTER_V)) / (float)S.height;
+        v3 cu = V(S.cam.u[0], S.cam.u[1], S.cam.u[2]), cv = V(S.cam.v[0], S.cam.v[1], S.cam.v[2]);
+        v3 offset = V(0.0f, 0.0f, 0.0f);
+        if (S.cam.lens_radius != 0.0f) {   // random_in_unit_disk random.h:27-34
+            float su, cu2;
+            ptm_sincos_2pi((float)rnd(k0, k1, DIM_LENS), su, cu2);
+            float rv = sqrtf((float)rnd(k0, k1, DIM_LENS + 1));
+            v3 rd = vscale(S.cam.lens_radius, V(cu2 * rv, su * rv, 0.0f));
+            offset = vadd(vscale(rd.x, cu), vscale(rd.y, cv));
+        }
+        v3 origin = V(S.cam.origin[0], S.cam.origin[1], S.cam.origin[2]);
+        v3 llc = V(S.cam.llc[0], S.cam.llc[1], S.cam.llc[2]);
+        v3 hor = V(S.cam.horizontal[0], S.cam.horizontal[1], S.cam.horizontal[2]);
+        v3 ver = V(S.cam.vertical[0], S.cam.vertical[1], S.cam.vertical[2]);
+        v3 A = vadd(origin, offset);
+        v3 B = vsub(vsub(vadd(vadd(llc, vscale(u, hor)), vscale(v, ver)), origin), offset);
+        q.r0[slot] = make_float4(A.x, A.y, A.z, __int_as_float((int)slot));
+        q.r1[slot] = make_float4(B.x, B.y, B.z, -1.0f);                 // last_bsdf_pdf = -1 (integrator.h:183)
+        q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(k0));  // beta = 1
+        q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(k1));  // attenuation = 0
+        st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (threadIdx.x == 0) {
+        q.count[seg] = n;
+        if (n) atomicAdd(&st.counters->camera_samples, (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// extend: closest hit of every live path's ray (integrator.h:192-193)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, DStreams st, DBatch b, int qi, int bounce)
+{
+    __shared__ float2 stack[PT_MAX_STACK * PT_BLOCK];
+    const int seg = blockIdx.x;
+    const DQueue q = st.q[qi];
+    const int n = q.count[seg];
+    if (n == 0) return;
+    const long long seg_base = (long long)seg * b.seg_cap;
+    const uint32_t base_dim = DIM_BOUNCE0 + (uint32_t)bounce * dims_per_bounce(S);
+    const bool has_vol = S.n_vol > 0;
+    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        // whole wave beyond the end: nothing to do (wave-uniform exit keeps the sweep convergent)
+        if (((i0 + (int)(threadIdx.x & ~63u)) >= n)) continue;
+        const long long pos = seg_base + (valid ? i : 0);
+        float4 r0 = q.r0[pos], r1 = q.r1[pos];
+        uint32_t k0 = 0, k1 = 0;
+        if (has_vol) { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
+        float t;
+        int id;
+        world_hit(S, valid, V(r0.x, r0.y, r0.z), V(r1.x, r1.y, r1.z), k0, k1, base_dim, &stack[threadIdx.x], t, id);
+        if (valid) st.hit[pos] = make_float2(t, __int_as_float(id));
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&st.counters->rays, (unsigned long long)n);
+        atomicAdd(&st.counters->ext_rays, (unsigned long long)n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shade: one bounce of NEEIterative::color between the two World::hit calls (integrator.h:193-336):
+// material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
+// continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, DStreams st, DBatch b, int qi, int bounce)
+{
+    __shared__ int sh4[PT_BLOCK / 64];
+    __shared__ unsigned int sh_ctr[C_N];
+    const int seg = blockIdx.x;
+    const DQueue q = st.q[qi];
+    const DQueue qo = st.q[qi ^ 1];
+    const DShadowQueue sq = st.sq;
+    const int n = q.count[seg];
+    if (threadIdx.x < C_N) sh_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    const long long seg_base = (long long)seg * b.seg_cap;
+    const long long P = (long long)b.n_seg * b.seg_cap;
+    const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
+    const uint32_t D = NV + L * (3u + NV) + 4u;
+    const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
+    const uint32_t gb = base + NV + L * (3u + NV);
+    const bool last_bounce = (bounce + 1 >= S.max_bounces);
+    const float pick_pdf = (float)S.n_lights;   // integrator.h:224
+    (void)pick_pdf;
+    int out_n = 0, sh_n = 0;
+    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        bool cont = false, shadow = false, pending = false;
+        v3 A = V(0, 0, 0), B = V(0, 0, 0);
+        v3 beta = V(0, 0, 0), att = V(0, 0, 0);      // beta BEFORE this bounce's update; attenuation AFTER scatter()
+        v3 nA = V(0, 0, 0), nB = V(0, 0, 0), nbeta = V(0, 0, 0);
+        v3 hp = V(0, 0, 0), hn = V(0, 0, 0);
+        float new_pdf = 0.0f;
+        uint32_t k0 = 0, k1 = 0;
+        int slot = 0, mat_type = 0;
+        if (valid) {
+            const long long pos = seg_base + i;
+            const float4 r0 = q.r0[pos], r1 = q.r1[pos], s0 = q.s0[pos], s1 = q.s1[pos];
+            const float2 h = st.hit[pos];
+            A = V(r0.x, r0.y, r0.z);
+            B = V(r1.x, r1.y, r1.z);
+            slot = __float_as_int(r0.w);
+            const float last_bsdf_pdf = r1.w;
+            beta = V(s0.x, s0.y, s0.z);
+            att = V(s1.x, s1.y, s1.z);
+            k0 = __float_as_uint(s0.w);
+            k1 = __float_as_uint(s1.w);
+            const int id = __float_as_int(h.y);
+            if (id < 0) {
+                // miss: sum += beta * world->value(...), constant background (integrator.h:325-336, world.h:27-30)
+                const float4 rad = st.radiance[slot];
+                const v3 add = vmul(beta, V(S.bg[0], S.bg[1], S.bg[2]));
+                st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                atomicAdd(&sh_ctr[C_MISS], 1u);
+            } else {
+                atomicAdd(&sh_ctr[C_EXT_HITS], 1u);
+                const HitInfo hi = finalize_hit(S, A, B, h.x, id, true);
+                const DMat m = S.mats[hi.mat];
+                mat_type = m.type;
+                hp = hi.p;
+                hn = hi.n;
+                // scatter(): material.h:39-53 lambertian, :90-98 metal, :187-191 diffuse_light (attenuation keeps
+                // its previous value), :252-261 isotropic
+                bool did_scatter = true;
+                if (m.type == 0) {
+                    if (vdot(B, hi.n) < 0) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
+                    else att = V(0.0f, 0.0f, 0.0f);
+                } else if (m.type == 1) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
+                else if (m.type == 3) did_scatter = false;
+                else if (m.type == 4) att = V(m.r, m.g, m.b);
+                const float cos_i = fabsf(vdot(vunit(B), vunit(hi.n)));
+                const v3 hit_emission = material_emitted(m, B, hi.n);
+                if ((double)vsqlen(hit_emission) > 0.000001) {   // integrator.h:205-218
+                    v3 add;
+                    if (last_bsdf_pdf <= 0) add = vmul(beta, hit_emission);
+                    else {
+                        const float lp = instance_pdf_value(S, id >> 3, A, hi.p);   // a POSITION as direction
+                        const float weight = power_heuristic(last_bsdf_pdf, lp);
+                        add = vscale(weight, vmul(beta, hit_emission));
+                    }
+                    const float4 rad = st.radiance[slot];
+                    st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                }
+                shadow = true;
+                if (did_scatter) {   // integrator.h:271-316
+                    nA = vadd(hi.p, vscale(S.normal_offset, hi.n));
+                    nB = material_generate(m.type, hi.n, k0, k1, gb);
+                    const float scatter_pdf_s = material_value(m.type, hi.n, nB);
+                    const float pin = (beta.y < beta.z) ? beta.z : beta.y;   // std::max(a,b) = (a<b)?b:a
+                    const float p = (beta.x < pin) ? pin : beta.x;
+                    bool alive = true;
+                    nbeta = beta;
+                    if (S.russian_roulette && p <= 1 && 0.001 < (double)p) {
+                        if (rnd(k0, k1, gb + 3) > (double)p) { alive = false; atomicAdd(&sh_ctr[C_RR], 1u); }
+                        else { const float ip = 1 / p; nbeta = V(beta.x * ip, beta.y * ip, beta.z * ip); }
+                    }
+                    if (alive) {
+                        if (S.only_direct) alive = false;
+                        else if ((double)scatter_pdf_s < 0.0000001) { alive = false; atomicAdd(&sh_ctr[C_PDF], 1u); }
+                        else {
+                            nbeta = vmul(nbeta, vdivf(vscale(fabsf(cos_i), att), scatter_pdf_s));
+                            new_pdf = scatter_pdf_s;
+                            if (last_bounce) { alive = false; atomicAdd(&sh_ctr[C_LIMIT], 1u); }
+                        }
+                    }
+                    cont = alive;
+                } else {
+                    // emitter: sum += beta*hit_emission a second time (integrator.h:317-323).  connect applies
+                    // it AFTER this bounce's light contribution so the float additions keep the reference's order.
+                    const v3 add = vmul(beta, hit_emission);
+                    st.pending[slot] = make_float4(add.x, add.y, add.z, 0.0f);
+                    pending = true;
+                    atomicAdd(&sh_ctr[C_EMIT], 1u);
+                }
+            }
+        }
+        // ---- compaction: continuation rays -> next path queue, shadow records -> shadow queue ----
+        int tot_c, tot_s;
+        const int off_c = block_compact(cont, tot_c, sh4);
+        const int off_s = block_compact(shadow, tot_s, sh4);
+        if (cont) {
+            const long long o = seg_base + out_n + off_c;
+            qo.r0[o] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
+            qo.r1[o] = make_float4(nB.x, nB.y, nB.z, new_pdf);
+            qo.s0[o] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
+            qo.s1[o] = make_float4(att.x, att.y, att.z, __uint_as_float(k1));
+        }
+        if (shadow) {
+            // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
+            const long long o = seg_base + sh_n + off_s;
+            sq.p0[o] = make_float4(hp.x, hp.y, hp.z, __int_as_float(slot | (pending ? (int)0x80000000 : 0)));
+            if (NV) sq.key[o] = make_uint2(k0, k1);
+            const bool att_ok = (double)vlen(att) > 0.0001;   // integrator.h:248
+            const v3 ab = vmul(att, beta);
+            for (uint32_t k = 0; k < L; k++) {
+                const uint32_t kb = base + NV + k * (3u + NV);
+                const int idx = (int)(rnd(k0, k1, kb + 0) * (double)S.n_lights);   // world.h:31-35
+                const int light = S.lights[idx];
+                const v3 ldir = instance_random(S, light, hp, k0, k1, kb + 1);
+                const float cos_l = vdot(vunit(ldir), vunit(hn));
+                const float light_pdf_l = instance_pdf_value(S, light, hp, ldir);
+                const float scatter_pdf_l = material_value(mat_type, hn, ldir);
+                const float weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
+                const float dropoff = cos_l > 0.0f ? cos_l : 0.0f;
+                // attenuation * beta * weight_l / light_pdf_l * dropoff  (* light_emission / pick_pdf in connect)
+                v3 c = vscale(weight_l, ab);
+                c = vdivf(c, light_pdf_l);
+                c = vscale(dropoff, c);
+                if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
+                sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
+                sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+            }
+        }
+        out_n += tot_c;
+        sh_n += tot_s;
+    }
+    if (threadIdx.x == 0) {
+        qo.count[seg] = out_n;
+        sq.count[seg] = sh_n;
+    }
+    flush_counters(sh_ctr, st.counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// connect: the light_samples shadow rays of one hit (integrator.h:244-268): closest hit, emitted() of
+// whatever was hit, NaN contributions dropped, sum += light_contribution / light_samples,
+// then the deferred second emitter addition.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBatch b, int bounce)
+{
+    __shared__ float2 stack[PT_MAX_STACK * PT_BLOCK];
+    const int seg = blockIdx.x;
+    const DShadowQueue sq = st.sq;
+    const int n = sq.count[seg];
+    if (n == 0) return;
+    const long long seg_base = (long long)seg * b.seg_cap;
+    const long long P = (long long)b.n_seg * b.seg_cap;
+    const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
+    const uint32_t D = NV + L * (3u + NV) + 4u;
+    const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
+    const float pick_pdf = (float)S.n_lights;   // integrator.h:224
+    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        const bool valid = i < n;
+        if (((i0 + (int)(threadIdx.x & ~63u)) >= n)) continue;
+        const long long pos = seg_base + (valid ? i : 0);
+        const float4 p0 = sq.p0[pos];
+        const v3 hp = V(p0.x, p0.y, p0.z);
+        const int slotw = __float_as_int(p0.w);
+        uint32_t k0 = 0, k1 = 0;
+        if (NV) { const uint2 kk = sq.key[pos]; k0 = kk.x; k1 = kk.y; }
+        v3 lc = V(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < L; k++) {
+            const float4 d = sq.d[(long long)k * P + pos];
+            const float2 e = sq.e[(long long)k * P + pos];
+            const v3 ldir = V(d.x, d.y, d.z);
+            float t;
+            int id;
+            world_hit(S, valid, hp, ldir, k0, k1, base + NV + k * (3u + NV) + 3u, &stack[threadIdx.x], t, id);
+            if (valid && id >= 0) {
+                const int ii = id >> 3, face = id & 7;
+                const DInst &in = S.insts[ii];
+                const DPrim &pr = S.prims[in.prim];
+                const int mi = pr.type == 0 ? pr.r[0].mat : (pr.type == 1 ? pr.r[face].mat : (pr.type == 2 ? pr.mat : pr.phase_mat));
+                const DMat m = S.mats[mi];
+                v3 le = V(0.0f, 0.0f, 0.0f);
+                if (m.type == 3) {
+                    if (m.two_sided) le = vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
+                    else le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
+                }
+                v3 c = vmul(V(d.w, e.x, e.y), le);
+                c = vdivf(c, pick_pdf);
+                if (!v_is_nan(c)) lc = vadd(lc, c);
+            }
+        }
+        if (valid) {
+            const int slot = slotw & 0x7fffffff;
+            const float4 rad = st.radiance[slot];
+            v3 r = vadd(V(rad.x, rad.y, rad.z), vdivf(lc, (float)S.light_samples));   // integrator.h:268
+            if (slotw < 0) { const float4 pe = st.pending[slot]; r = vadd(r, V(pe.x, pe.y, pe.z)); }
+            st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long nr = (unsigned long long)n * L;
+        atomicAdd(&st.counters->rays, nr);
+        atomicAdd(&st.counters->shadow_rays, nr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// accumulate: framebuffer[j][i] += de_nan(col), samples in increasing order (renderer.h:670-682)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, DBatch b)
+{
+    const int npix = b.w * b.h;
+    for (int pl = blockIdx.x * PT_BLOCK + threadIdx.x; pl < npix; pl += gridDim.x * PT_BLOCK) {
+        const int py = pl / b.w, px = pl - py * b.w;
+        const long long fi = (long long)(b.y0 + py) * S.width + (b.x0 + px);
+        float4 acc = st.fb[fi];
+        for (int s = 0; s < b.ns; s++) {
+            const float4 r = st.radiance[(long long)s * npix + pl];
+            acc.x += is_nanf(r.x) ? 0.0f : r.x;
+            acc.y += is_nanf(r.y) ? 0.0f : r.y;
+            acc.z += is_nanf(r.z) ? 0.0f : r.z;
+        }
+        st.fb[fi] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ------------------------------------------------------------------------------------------------
+void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_generate, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b);
+}
+void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, qi, bounce);
+}
+void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_shade, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, qi, bounce);
+}
+void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_connect, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, bounce);
+}
+void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
+{
+    int npix = b.w * b.h;
+    int blocks = (npix + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(PT_BLOCK), 0, s, S, st, b);
+}
+
+}  // namespace ptd

@@ -1,0 +1,168 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libpathtrace_hip.so); the oracle (CPU restatement, stream mode: same counter RNG, same portable math) is
+only the checker.
+
+Bar (floating point path, tolerance stated here): the per-pixel linear framebuffer SUM must be BIT-IDENTICAL
+to the oracle in stream mode -- tolerance 0 ulp -- together with every path counter.  This is stricter than
+the fallback tolerance of SURVEY.md 8(d) (1e-3 relative on 99.5 % of pixel-channels); if a future change makes
+the arithmetic diverge, that fallback is what `assert_close_enough` checks and the test says so loudly.
+"""
+import numpy as np
+import pytest
+
+import pathtrace_amd as pt
+from conftest import SCENES, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def oracle_cfg(oracle, w, h, spp, **kw):
+    return oracle.make_config(w, h, spp, **kw)
+
+
+def gpu_render(scene, w, h, spp, seed=0, max_paths=0, rect=None, **kw):
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, seed=seed, max_paths_in_flight=max_paths,
+                    max_bounces=kw.get("max_bounces", 10), light_samples=kw.get("light_samples", 4),
+                    russian_roulette=kw.get("russian_roulette", True), only_direct=kw.get("only_direct", False))
+    fb = r.render(spp, rect)
+    ctr = r.counters()
+    r.close()
+    return fb, ctr
+
+
+def assert_bit_identical(gpu, ref, what):
+    same = bits(gpu) == bits(ref)
+    # +0.0 / -0.0 are the same radiance
+    same |= (gpu == ref)
+    if not same.all():
+        bad = np.argwhere(~same)
+        j, i, c = bad[0]
+        rel = np.abs(gpu - ref) / np.maximum(np.abs(ref), 1e-30)
+        raise AssertionError(f"{what}: {len(bad)} of {same.size} pixel-channels differ; first at (i={i}, j={j}, c={c}): "
+                             f"gpu={gpu[j, i, c]!r} oracle={ref[j, i, c]!r}; max rel err {rel.max():.3g}")
+
+
+CTR_MAP = {"rays": "rays", "extension_rays": "ext_rays", "extension_hits": "ext_hits", "shadow_rays": "shadow_rays",
+           "term_miss": "term_miss", "term_rr": "term_rr", "term_emitter": "term_emitter", "term_pdf": "term_pdf",
+           "term_bounce_limit": "term_bounce_limit"}
+
+
+def assert_counters(gc, oc, what):
+    for g, o in CTR_MAP.items():
+        assert gc[g] == oc[o], f"{what}: counter {g}: gpu {gc[g]} oracle {oc[o]}"
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_bit_exact_vs_oracle_stream_64x64x4(oracle, scene):
+    w, h, spp = 64, 64, 4
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=0)
+    gpu, gc = gpu_render(scene, w, h, spp)
+    assert_bit_identical(gpu, ref, scene)
+    assert_counters(gc, oc, scene)
+    assert gc["camera_samples"] == w * h * spp
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_bit_exact_config1_size_200x200x16(oracle, scene):
+    # BASELINE config 1 size on all three scenes (the oracle needs ~1 s with 8+ threads)
+    w, h, spp = 200, 200, 16
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=0)
+    gpu, gc = gpu_render(scene, w, h, spp)
+    assert_bit_identical(gpu, ref, scene)
+    assert_counters(gc, oc, scene)
+
+
+@pytest.mark.parametrize("kw", [dict(light_samples=1), dict(russian_roulette=False), dict(only_direct=True),
+                                dict(max_bounces=3, light_samples=2), dict(max_bounces=1), dict(light_samples=7)])
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume"])
+def test_bit_exact_config_variants(oracle, scene, kw):
+    w, h, spp = 96, 54, 6   # 16:9, ~43 % of the camera rays miss the box
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp, **kw), seed=3)
+    gpu, gc = gpu_render(scene, w, h, spp, seed=3, **kw)
+    assert_bit_identical(gpu, ref, f"{scene} {kw}")
+    assert_counters(gc, oc, f"{scene} {kw}")
+
+
+def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
+    # size-independent property: the image is a pure function of (pixel, sample, seed); how the work is cut into
+    # batches (max_paths_in_flight), tiles (NaiveSpiral) or sample ranges must not change a single bit.
+    scene, w, h, spp = "cornell_box_small_lights", 160, 90, 8
+    whole, c0 = gpu_render(scene, w, h, spp)
+    small, c1 = gpu_render(scene, w, h, spp, max_paths=5000)   # many ragged batches, rows split into bands
+    assert np.array_equal(bits(whole), bits(small)) and c0 == c1
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, max_paths_in_flight=20000)
+    for rect in pt.spiral_tiles(w, h, 64, 64):   # 3x2 tiles, clamped at the right/top edge
+        r.render_async(0, 3, rect)
+        r.render_async(3, spp, rect)
+    tiled = r.framebuffer()
+    assert np.array_equal(bits(whole), bits(tiled)) and r.counters() == c0
+    # a single pixel / single sample batch (ragged minimum)
+    r.clear()
+    r.render_async(5, 6, (17, 23, 18, 24))
+    one = r.framebuffer()
+    ref, _ = oracle.Scene.from_json(scene_path(scene)).sample_stream(oracle_cfg(oracle, w, h, spp), 17, 23, 5)
+    assert np.array_equal(bits(one[23, 17]), bits(ref))
+    assert one.sum() == one[23, 17].sum()
+    r.close()
+
+
+def test_seed_changes_the_stream_but_not_the_estimate(oracle):
+    scene, w, h, spp = "cornell_box", 64, 64, 64
+    a, _ = gpu_render(scene, w, h, spp, seed=1)
+    b, _ = gpu_render(scene, w, h, spp, seed=2)
+    assert not np.array_equal(a, b)
+    # same estimator: image means agree within Monte-Carlo error (cornell_box radiance is well behaved)
+    assert np.allclose(a.mean(axis=(0, 1)), b.mean(axis=(0, 1)), rtol=0.03)
+
+
+def test_statistical_agreement_with_reference_fixture():
+    # L3 of the parity ladder: GPU at 256 spp vs the REAL reference's 16 spp fixture (different RNG streams),
+    # on radiance clamped at 4.0 per channel per sample-mean to tame fireflies (the clamp is stated here).
+    import os
+    from conftest import GOLD
+    scene, w, h = "cornell_box", 200, 200
+    gold = np.load(os.path.join(GOLD, f"fb_{scene}_200x200x16.npy")) / 16.0
+    gpu, _ = gpu_render(scene, w, h, 256)
+    gpu = gpu / 256.0
+    g, r = np.minimum(gpu, 4.0), np.minimum(gold, 4.0)
+    # per-channel image mean within 1.5 % (16 spp reference noise dominates)
+    assert np.allclose(g.mean(axis=(0, 1)), r.mean(axis=(0, 1)), rtol=0.015), (g.mean(axis=(0, 1)), r.mean(axis=(0, 1)))
+    # 8x8 block means (625 blocks): 99 % within 15 % + small absolute floor
+    gb = g.reshape(25, 8, 25, 8, 3).mean(axis=(1, 3))
+    rb = r.reshape(25, 8, 25, 8, 3).mean(axis=(1, 3))
+    ok = np.abs(gb - rb) <= 0.15 * np.maximum(gb, rb) + 0.01
+    assert ok.mean() > 0.99, ok.mean()
+    # the directly visible light is 2 * Le = 1.2 in both, pixel (i=100, j=199 is ceiling; light seen at top centre)
+    lit_g, lit_r = np.isclose(gpu, 1.2, atol=1e-3).all(axis=2), np.isclose(gold, 1.2, atol=1e-3).all(axis=2)
+    assert lit_r.sum() > 50 and (lit_g & lit_r).sum() >= 0.9 * lit_r.sum()
+
+
+def test_async_protocol_and_errors():
+    sc = pt.Scene(scene_path("cornell_box"), 256, 256)
+    r = pt.Renderer(sc)
+    r.render_async(0, 32)
+    done, samples, rays = r.poll()          # non-blocking, may or may not be finished
+    r.wait()
+    done, samples, rays = r.poll()
+    assert done and samples == 256 * 256 * 32 and rays == r.counters()["rays"]
+    with pytest.raises(pt.PathtraceError):
+        r.render_async(0, 1, (0, 0, 300, 10))   # outside the film
+    with pytest.raises(pt.PathtraceError):
+        r.render_async(4, 4)                    # empty sample range
+    r.clear()
+    assert r.framebuffer().sum() == 0 and r.counters()["rays"] == 0
+    r.close()
+    # unsupported material is refused loudly, not silently approximated
+    import json
+    s = json.load(open(scene_path("cornell_box")))
+    s["materials"].append({"id": "glass", "type": "dielectric", "data": {"ior": 1.5}})
+    s["instances"][5]["primitive"] = {"id": "gbox"}
+    s["primitives"].append({"id": "gbox", "type": "box", "material": {"id": "glass"}, "size": [165, 165, 165]})
+    with pytest.raises(pt.PathtraceError):
+        pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))
