@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the per-pixel NEE path-tracing hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): scenes/cornell_box.json, 1920x1080, max_bounces 10, light_samples 4, russian
+roulette on, normal_offset 1e-4.  One *step* = one wavefront pass over the whole frame at SPP_PER_STEP*N samples per
+pixel (one batch of ~8.3 M camera samples per GPU); the default K = 256 steps at N = 1 is exactly the 1024 spp of
+configs[1].  "ray" = one World::hit query, extension + shadow, the reference's own unit (integrator.h:192,247).
+
+N > 1: one process per GPU; the image is partitioned by 128x128 tile in NaiveSpiral order, tile k -> rank k mod N
+(SURVEY.md 8e), every rank renders its tiles with no communication, and ONE RCCL sum-reduce of the framebuffer to
+rank 0 ends the timed region.  Per-GPU work is held fixed as N grows (samples per step scale with N): "weak".
+
+The timed region holds only GPU work on device-resident data (scene tables + streams live in HBM; there are no host
+buffers on the path).  Rank 0 also reports:
+  roofline      the dominant kernel's algorithmic bytes / its HIP-event time, against 8 TB/s (SURVEY.md 8d byte model)
+  cpu_baseline  the oracle (CPU restatement, stream mode, all host cores) on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
+SPP_PER_STEP = 4
+TILE = 128
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# SURVEY.md 8(d) byte model, per unit of each kernel
+BYTES_PER_EXT_RAY_EXTEND = 32 + 16          # read ray, write hit
+BYTES_PER_SHADOW_RAY_CONNECT = 48 + 24      # read shadow record, radiance RMW
+PIPELINE_BYTES_PER_RAY_16x9 = 153.0         # whole pipeline, cornell_box 16:9
+
+
+def shade_bytes(E, H, S):
+    # read hit+ray+state 96 per E, write state 48 per H, continuation ray 32 per (E - samples), shadow record 48 per S
+    return 96 * E + 48 * H + 48 * S
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", default=SCENE)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n:
+        if world == 1 and n > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        n = world
+
+    import torch  # device memory for the framebuffer + torch.distributed (RCCL) only
+    import pathtrace_amd as pt
+
+    if not torch.cuda.is_available() or pt.device_count() < 1:
+        sys.exit("bench.py: no MI355X visible -- the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if n > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+
+    scene = pt.Scene(args.scene, WIDTH, HEIGHT)
+    r = pt.Renderer(scene, device=local_rank, seed=0)
+    # render straight into a torch tensor so that the final reduce needs no copy
+    fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
+
+    spp_step = SPP_PER_STEP * n
+    if n == 1:
+        my_tiles = [(0, 0, WIDTH, HEIGHT)]
+    else:
+        tiles = pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE)
+        my_tiles = tiles[rank::n]
+
+    def step(i):
+        r.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
+
+    def sync():
+        r.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    r.clear()
+    r.set_profiling(True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    r.wait()
+    if dist is not None:
+        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)   # the one exchange of the path
+    sync()
+    dt = time.perf_counter() - t0
+
+    ctr = r.counters()
+    kt = r.kernel_times()
+    rays = torch.tensor([ctr["rays"], ctr["camera_samples"], ctr["extension_rays"], ctr["extension_hits"],
+                         ctr["shadow_rays"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    total_rays, total_samples, E, H, S = [float(x) for x in rays.tolist()]
+    dt = float(tmax.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the render stream) ----
+        model_bytes = {
+            "extend": BYTES_PER_EXT_RAY_EXTEND * kt["extend"]["units"],
+            "connect": BYTES_PER_SHADOW_RAY_CONNECT * kt["connect"]["units"],
+            "shade": shade_bytes(ctr["extension_rays"], ctr["extension_hits"], ctr["shadow_rays"]),
+        }
+        dom = max(("extend", "shade", "connect"), key=lambda k: kt[k]["ms"])
+        launches = max(kt[dom]["launches"], 1)
+        avg_ms = kt[dom]["ms"] / launches
+        achieved = (model_bytes[dom] / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                    "bytes_per_launch_model": round(model_bytes[dom] / launches, 1),
+                    "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
+                    "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
+                    "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import pt_oracle
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            osc = pt_oracle.Scene.from_json(args.scene)
+            spp_cpu = 2
+            cfg = pt_oracle.make_config(WIDTH, HEIGHT, spp_cpu)
+            c0 = time.perf_counter()
+            _, octr = osc.render_stream(cfg, seed=0, threads=cores)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round(octr["rays"] / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays), oracle stream mode, "
+                             f"{cores} threads, {cdt:.2f} s wall"}
+
+        out = {
+            "metric": "Mrays/sec + achieved HBM GB/s %peak, cornell_box 1080p@1024spp, 1/2/4/8 GPU",
+            "value": round(total_rays / dt / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "scenes/cornell_box.json 1920x1080, iterative NEE path tracing, max_bounces 10, "
+                                   "light_samples 4, russian roulette, %d spp per step per frame (K=256 at N=1 is 1024 spp)" % spp_step,
+                       "spp_total": spp_step * args.steps, "camera_samples": int(total_samples), "rays": int(total_rays),
+                       "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
+                       "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
+                       "partition": "whole frame" if n == 1 else f"128x128 tiles, spiral order, tile k -> rank k mod {n}; 1 RCCL reduce"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,10 @@ void pt_destroy(pt_ctx *ctx);
  * renderer.h:30) and return immediately.  Replaces the body of Tiled::compute (renderer.h:626-691) for one
  * tile: jitter + camera::get_ray + NEEIterative::color + framebuffer[j][i] += de_nan(col). */
 int pt_render_async(pt_ctx *ctx, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t spp_begin, int32_t spp_end);
+/* Same for a set of pixel rects (image tiles, NaiveSpiral::next queue.h:121-127) rendered together as one
+ * wavefront batch: rects = n_rects * {x0, y0, x1, y1}.  This is how one GPU renders the tiles it owns in a
+ * tile-partitioned multi-GPU render without paying one small batch per tile. */
+int pt_render_tiles_async(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end);
 /* Non-blocking progress (Tiled::sync_progress renderer.h:605-620 reads samples_done[]):
  * returns 1 when everything enqueued so far has finished, 0 if still running, < 0 on error. */
 int pt_poll(pt_ctx *ctx, uint64_t *samples_done, uint64_t *rays_done);

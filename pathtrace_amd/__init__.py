@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpathtrace_hip.so")
+LIB_PATH = os.environ.get("PATHTRACE_HIP_LIB") or os.path.join(HERE, "lib", "libpathtrace_hip.so")
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = range(5)
 PRIM_RECT, PRIM_BOX, PRIM_SPHERE, PRIM_VOLUME = range(4)
@@ -88,7 +88,7 @@ class HostConfig(C.Structure):
 
 
 # every symbol include/pathtrace_hip.h declares
-EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_poll", "pt_wait", "pt_read_framebuffer",
+EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
            "pt_read_last_batch_radiance", "pt_last_error", "pt_abi_version", "pt_device_count",
@@ -113,6 +113,7 @@ def lib():
     L.pt_destroy.argtypes = [vp]
     L.pt_destroy.restype = None
     L.pt_render_async.argtypes = [vp] + [C.c_int32] * 6
+    L.pt_render_tiles_async.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
     L.pt_poll.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pt_wait.argtypes = [vp]
     L.pt_read_framebuffer.argtypes = [vp, fp]
@@ -253,6 +254,11 @@ class Renderer:
     def render_async(self, spp_begin, spp_end, rect=None):
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.width, self.height)
         _check(lib().pt_render_async(self._h, x0, y0, x1, y1, spp_begin, spp_end), "pt_render_async")
+
+    def render_tiles_async(self, rects, spp_begin, spp_end):
+        flat = [int(v) for r in rects for v in r]
+        arr = (C.c_int32 * len(flat))(*flat)
+        _check(lib().pt_render_tiles_async(self._h, len(rects), arr, spp_begin, spp_end), "pt_render_tiles_async")
 
     def poll(self):
         s, r = C.c_uint64(), C.c_uint64()

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,10 @@ struct pt_ctx {
     DCounters *host_ctr = nullptr;   // pinned mirror, refreshed after every batch
     DBatch last_batch{};
     bool have_last = false;
+    // tile table of the current / last pt_render_tiles_async call (device copy + host mirror for reuse)
+    DTile *d_tiles = nullptr;
+    size_t d_tiles_cap = 0;
+    std::vector<DTile> h_tiles;
     // profiling
     bool profiling = false;
     std::vector<TimedLaunch> timed;
@@ -198,6 +203,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             break;
         default: set_err("pt_create: primitive %d: unsupported type %d", i, p.type); return -1;
         }
+        for (int f = 0; f < 8; f++) d.hit_mat[f] = (p.type == PT_PRIM_VOLUME) ? p.phase_material : p.material;
         prims[i] = d;
     }
     std::vector<DInst> insts(sc->n_instances);
@@ -287,8 +293,9 @@ static int alloc_streams(pt_ctx *c)
 extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config)
 {
     if (!scene || !config) { set_err("pt_create: null argument"); return nullptr; }
-    if (config->width < 1 || config->height < 1 || config->max_bounces < 0 || config->light_samples < 0) {
-        set_err("pt_create: bad config");
+    if (config->width < 1 || config->height < 1 || config->max_bounces < 0 || config->light_samples < 1) {
+        // light_samples = 0 makes the reference divide by zero (integrator.h:268) and trip its NaN assertion
+        set_err("pt_create: bad config (width/height >= 1, max_bounces >= 0, light_samples >= 1 required)");
         return nullptr;
     }
     int ndev = 0;
@@ -372,37 +379,97 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     return 0;
 }
 
+// One batch group = consecutive bands whose pixel total fits the path slots; rendered for every sample chunk.
+static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::vector<int> &band_h, size_t g0, size_t g1,
+                        size_t tile_off, int32_t spp_begin, int32_t spp_end)
+{
+    int64_t npix = 0;
+    for (size_t i = g0; i < g1; i++) npix += (int64_t)bands[i].w * band_h[i];
+    const int ns_fit = (int)std::max<int64_t>(1, c->P / npix);
+    for (int s = spp_begin; s < spp_end;) {
+        const int ns = std::min(ns_fit, spp_end - s);
+        DBatch b{};
+        b.x0 = bands[g0].x0; b.y0 = bands[g0].y0; b.w = bands[g0].w;
+        b.n_tiles = (int)(g1 - g0);
+        b.tiles = c->d_tiles + tile_off;
+        b.npix = (int)npix;
+        b.s0 = s; b.ns = ns;
+        b.seg_cap = c->seg_cap;
+        b.n_paths = npix * ns;
+        b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
+        if (run_batch(c, b)) return -1;
+        s += ns;
+    }
+    return 0;
+}
+
+extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end)
+{
+    if (!c || !rects || n_rects < 1) { set_err("pt_render_tiles_async: bad argument"); return -1; }
+    if (spp_begin < 0 || spp_end <= spp_begin) { set_err("pt_render_tiles_async: bad sample range [%d,%d)", spp_begin, spp_end); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->profiling) c->timed.clear();
+    // rects -> bands of at most P pixels each
+    std::vector<DTile> bands;
+    std::vector<int> band_h;
+    for (int r = 0; r < n_rects; r++) {
+        const int x0 = rects[4 * r], y0 = rects[4 * r + 1], x1 = rects[4 * r + 2], y1 = rects[4 * r + 3];
+        if (x0 < 0 || y0 < 0 || x1 > c->cfg.width || y1 > c->cfg.height || x0 >= x1 || y0 >= y1) {
+            set_err("pt_render_tiles_async: rect %d = [%d,%d)x[%d,%d) is empty or outside the %dx%d film", r, x0, x1, y0, y1,
+                    c->cfg.width, c->cfg.height);
+            return -1;
+        }
+        const int w = x1 - x0;
+        if (w > c->P) { set_err("pt_render_tiles_async: rect width %d exceeds max_paths_in_flight", w); return -1; }
+        const int rows_fit = (int)std::max<int64_t>(1, c->P / w);
+        for (int yb = y0; yb < y1; yb += rows_fit) {
+            const int hb = std::min(rows_fit, y1 - yb);
+            bands.push_back(DTile{x0, yb, w, 0});
+            band_h.push_back(hb);
+        }
+    }
+    // greedy groups of consecutive bands with <= P pixels; tile table = per group [bands..., sentinel]
+    std::vector<DTile> table;
+    struct Group { size_t g0, g1, off; };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < bands.size();) {
+        int64_t npix = 0;
+        size_t j = i;
+        const size_t off = table.size();
+        while (j < bands.size() && npix + (int64_t)bands[j].w * band_h[j] <= c->P) {
+            DTile t = bands[j];
+            t.pix0 = (int)npix;
+            table.push_back(t);
+            npix += (int64_t)bands[j].w * band_h[j];
+            j++;
+        }
+        table.push_back(DTile{0, 0, 1, (int)npix});
+        groups.push_back({i, j, off});
+        i = j;
+    }
+    // upload the table unless it is the one already on the device (the usual case: one call per sample chunk)
+    const bool same = table.size() == c->h_tiles.size() &&
+                      (table.empty() || memcmp(table.data(), c->h_tiles.data(), table.size() * sizeof(DTile)) == 0);
+    if (!same) {
+        HIP_TRY(hipStreamSynchronize(c->stream));   // earlier batches may still read the old table
+        if (table.size() > c->d_tiles_cap) {
+            if (dev_alloc(c, &c->d_tiles, table.size() * 2)) return -1;
+            c->d_tiles_cap = table.size() * 2;
+        }
+        HIP_TRY(hipMemcpy(c->d_tiles, table.data(), table.size() * sizeof(DTile), hipMemcpyHostToDevice));
+        c->h_tiles = table;
+    }
+    for (const Group &g : groups)
+        if (render_group(c, bands, band_h, g.g0, g.g1, g.off, spp_begin, spp_end)) return -1;
+    HIP_TRY(hipEventRecord(c->done_ev, c->stream));
+    return 0;
+}
+
 extern "C" int pt_render_async(pt_ctx *c, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t spp_begin, int32_t spp_end)
 {
     if (!c) { set_err("pt_render_async: null ctx"); return -1; }
-    if (x0 < 0 || y0 < 0 || x1 > c->cfg.width || y1 > c->cfg.height || x0 >= x1 || y0 >= y1 || spp_begin < 0 || spp_end <= spp_begin) {
-        set_err("pt_render_async: bad rect/sample range [%d,%d)x[%d,%d) spp [%d,%d)", x0, x1, y0, y1, spp_begin, spp_end);
-        return -1;
-    }
-    HIP_TRY(hipSetDevice(c->device));
-    if (c->profiling) { c->timed.clear(); }
-    const int w = x1 - x0;
-    // rows per band so that one sample of a band fits; then as many samples per batch as fit
-    const int64_t rows_fit = std::max<int64_t>(1, c->P / w);
-    if (w > c->P) { set_err("pt_render_async: rect width %d exceeds max_paths_in_flight", w); return -1; }
-    for (int yb = y0; yb < y1;) {
-        const int hb = (int)std::min<int64_t>(rows_fit, y1 - yb);
-        const int64_t npix = (int64_t)w * hb;
-        const int ns_fit = (int)std::max<int64_t>(1, c->P / npix);
-        for (int s = spp_begin; s < spp_end;) {
-            const int ns = std::min(ns_fit, spp_end - s);
-            DBatch b{};
-            b.x0 = x0; b.y0 = yb; b.w = w; b.h = hb; b.s0 = s; b.ns = ns;
-            b.seg_cap = c->seg_cap;
-            b.n_paths = npix * ns;
-            b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
-            if (run_batch(c, b)) return -1;
-            s += ns;
-        }
-        yb += hb;
-    }
-    HIP_TRY(hipEventRecord(c->done_ev, c->stream));
-    return 0;
+    const int32_t r[4] = {x0, y0, x1, y1};
+    return pt_render_tiles_async(c, 1, r, spp_begin, spp_end);
 }
 
 extern "C" int pt_poll(pt_ctx *c, uint64_t *samples_done, uint64_t *rays_done)

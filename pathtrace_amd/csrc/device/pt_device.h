@@ -14,13 +14,14 @@ struct DRect {           // rect (reference primitive.h:120-183) in its XZ-canon
     float ny;            // 2*normal-1 = +1 / -1 (primitive.h:212)
     int32_t mat;
 };
-struct DPrim {           // 240 bytes
+struct DPrim {           // 272 bytes
     int32_t type, mat;
     int32_t boundary;    // volume: prim index
     int32_t phase_mat;   // volume
     float density;       // volume
     float cx, cy, cz, radius;  // sphere
     int32_t pad[3];
+    int32_t hit_mat[8];  // rec.mat_ptr by face: rect/sphere [0] = mat, box [0..5] = mat, volume [0] = phase_mat
     DRect r[6];          // rect: r[0];  box: the six sides in primitive.h:232-240 order
 };
 struct DInst {           // 112 bytes
@@ -96,11 +97,18 @@ struct DCounters {
     unsigned long long rays, ext_rays, ext_hits, shadow_rays;
     unsigned long long term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
 };
+struct DTile { int32_t x0, y0, w, pix0; };   // pix0 = first batch-local pixel index of this tile
 struct DBatch {
-    int32_t x0, y0, w, h;        // pixel rect of the batch
+    // the batch covers n_tiles pixel rects (image tiles, reference queue.h:121-127); batch-local pixel pl lives
+    // in the tile t with tiles[t].pix0 <= pl < tiles[t+1].pix0, row-major inside the tile.  n_tiles == 1 uses
+    // (x0, y0, w) directly.
+    int32_t x0, y0, w;
+    int32_t n_tiles;
+    const DTile *tiles;          // device array [n_tiles + 1] (last entry: pix0 = npix), only read when n_tiles > 1
+    int32_t npix;                // pixels in the batch
     int32_t s0, ns;              // first sample index, samples in the batch
     int32_t n_seg, seg_cap;      // segmentation of the P = n_seg*seg_cap slots
-    int64_t n_paths;             // w*h*ns  (<= P)
+    int64_t n_paths;             // npix*ns  (<= P)
 };
 struct DStreams {
     DQueue q[2];

@@ -325,10 +325,14 @@ DEVI HitInfo finalize_hit(const DScene &S, v3 A, v3 B, float t, int id, bool nee
     v3 pl = vadd(Al, vscale(t, Bl));   // r.point_at_parameter(t) in local space
     v3 nl;
     HitInfo h;
-    if (pr.type == 0) { nl = rect_normal(pr.r[0], Bl); h.mat = pr.r[0].mat; }
-    else if (pr.type == 1) { nl = rect_normal(pr.r[face], Bl); h.mat = pr.r[face].mat; }
-    else if (pr.type == 2) { nl = vdivf(vsub(pl, V(pr.cx, pr.cy, pr.cz)), pr.radius); h.mat = pr.mat; }
-    else { nl = V(1.0f, 0.0f, 0.0f); h.mat = pr.phase_mat; }
+    // rec.mat_ptr comes from one table load (hit_mat[face], resolved on the host).  Do NOT turn this back into a
+    // per-type chain of loads through `pr`: hipcc 7.2 merges such loads into one load behind an address select
+    // and materialises the last branch's address on only one predecessor path (seen in the gfx950 ISA; it
+    // faulted on volume hits).
+    h.mat = pr.hit_mat[face];
+    if (pr.type <= 1) nl = rect_normal(pr.r[face], Bl);   // rect: face = 0
+    else if (pr.type == 2) nl = vdivf(vsub(pl, V(pr.cx, pr.cy, pr.cz)), pr.radius);
+    else nl = V(1.0f, 0.0f, 0.0f);
     h.p = xf_point(in.fwd, pl);
     h.n = need_normal ? xf_normal(in.inv, nl) : V(0.0f, 0.0f, 0.0f);
     return h;
@@ -482,6 +486,23 @@ DEVI int block_compact(bool pred, int &total, int *sh4)
     total = tot;
     return off + woff;
 }
+// batch-local pixel -> film pixel (i, j)
+DEVI void batch_pixel(const DBatch &b, int pl, int &pi, int &pj)
+{
+    int x0 = b.x0, y0 = b.y0, w = b.w;
+    if (b.n_tiles > 1) {
+        int lo = 0, hi = b.n_tiles - 1;          // last tile with pix0 <= pl
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (b.tiles[mid].pix0 <= pl) lo = mid; else hi = mid - 1;
+        }
+        const DTile t = b.tiles[lo];
+        x0 = t.x0; y0 = t.y0; w = t.w; pl -= t.pix0;
+    }
+    const int py = pl / w;
+    pi = x0 + (pl - py * w);
+    pj = y0 + py;
+}
 enum { C_SAMPLES = 0, C_RAYS, C_EXT, C_EXT_HITS, C_SHADOW, C_MISS, C_RR, C_EMIT, C_PDF, C_LIMIT, C_N };
 DEVI void flush_counters(unsigned int *sh_ctr, DCounters *g)
 {
@@ -501,14 +522,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
     const long long seg_base = (long long)seg * b.seg_cap;
     long long remaining = b.n_paths - seg_base;
     const int n = remaining <= 0 ? 0 : (remaining < b.seg_cap ? (int)remaining : b.seg_cap);
-    const int npix = b.w * b.h;
+    const int npix = b.npix;
     DQueue q = st.q[0];
     for (int i = threadIdx.x; i < n; i += PT_BLOCK) {
         const long long slot = seg_base + i;
         const int s_local = (int)(slot / npix);
         const int pl = (int)(slot - (long long)s_local * npix);
-        const int py = pl / b.w, px = pl - py * b.w;
-        const int pi = b.x0 + px, pj = b.y0 + py;
+        int pi, pj;
+        batch_pixel(b, pl, pi, pj);
         const uint32_t pixel = (uint32_t)(pj * S.width + pi);
         const uint32_t sample = (uint32_t)(b.s0 + s_local);
         const uint32_t k0 = mix_lowbias32(pixel ^ S.seed_k0);
@@ -780,8 +801,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBa
                 const int ii = id >> 3, face = id & 7;
                 const DInst &in = S.insts[ii];
                 const DPrim &pr = S.prims[in.prim];
-                const int mi = pr.type == 0 ? pr.r[0].mat : (pr.type == 1 ? pr.r[face].mat : (pr.type == 2 ? pr.mat : pr.phase_mat));
-                const DMat m = S.mats[mi];
+                const DMat m = S.mats[pr.hit_mat[face]];
                 v3 le = V(0.0f, 0.0f, 0.0f);
                 if (m.type == 3) {
                     if (m.two_sided) le = vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
@@ -812,10 +832,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBa
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, DBatch b)
 {
-    const int npix = b.w * b.h;
+    const int npix = b.npix;
     for (int pl = blockIdx.x * PT_BLOCK + threadIdx.x; pl < npix; pl += gridDim.x * PT_BLOCK) {
-        const int py = pl / b.w, px = pl - py * b.w;
-        const long long fi = (long long)(b.y0 + py) * S.width + (b.x0 + px);
+        int pi, pj;
+        batch_pixel(b, pl, pi, pj);
+        const long long fi = (long long)pj * S.width + pi;
         float4 acc = st.fb[fi];
         for (int s = 0; s < b.ns; s++) {
             const float4 r = st.radiance[(long long)s * npix + pl];
@@ -848,7 +869,7 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
-    int npix = b.w * b.h;
+    int npix = b.npix;
     int blocks = (npix + PT_BLOCK - 1) / PT_BLOCK;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(PT_BLOCK), 0, s, S, st, b);

@@ -102,6 +102,16 @@ def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
         r.render_async(3, spp, rect)
     tiled = r.framebuffer()
     assert np.array_equal(bits(whole), bits(tiled)) and r.counters() == c0
+    # all tiles of two "ranks" as two multi-rect batches (tile k -> rank k mod 2), bands forced by a small slot budget
+    r.clear()
+    tiles = pt.spiral_tiles(w, h, 64, 64)
+    for rank in range(2):
+        r.render_tiles_async(tiles[rank::2], 0, spp)
+    assert np.array_equal(bits(whole), bits(r.framebuffer())) and r.counters() == c0
+    r2 = pt.Renderer(sc, max_paths_in_flight=3000)
+    r2.render_tiles_async(tiles[1::2] + tiles[0::2], 0, spp)
+    assert np.array_equal(bits(whole), bits(r2.framebuffer())) and r2.counters() == c0
+    r2.close()
     # a single pixel / single sample batch (ragged minimum)
     r.clear()
     r.render_async(5, 6, (17, 23, 18, 24))
@@ -121,26 +131,41 @@ def test_seed_changes_the_stream_but_not_the_estimate(oracle):
     assert np.allclose(a.mean(axis=(0, 1)), b.mean(axis=(0, 1)), rtol=0.03)
 
 
-def test_statistical_agreement_with_reference_fixture():
-    # L3 of the parity ladder: GPU at 256 spp vs the REAL reference's 16 spp fixture (different RNG streams),
-    # on radiance clamped at 4.0 per channel per sample-mean to tame fireflies (the clamp is stated here).
+@pytest.mark.parametrize("scene", SCENES)
+def test_statistical_agreement_with_reference_fixture(scene):
+    # L3 of the parity ladder: same estimator, different random streams.  Like for like: the GPU renders
+    # BASELINE config 1 (200x200x16) with 8 seeds; the REAL reference's fixture (one draw from the reference's
+    # own stream) must look like a ninth seed.  The estimator is heavy tailed, so per-pixel
+    # 16-spp means are clamped at 1.0 on both sides before comparing (clamp stated here; tolerances below).
     import os
     from conftest import GOLD
-    scene, w, h = "cornell_box", 200, 200
-    gold = np.load(os.path.join(GOLD, f"fb_{scene}_200x200x16.npy")) / 16.0
-    gpu, _ = gpu_render(scene, w, h, 256)
-    gpu = gpu / 256.0
-    g, r = np.minimum(gpu, 4.0), np.minimum(gold, 4.0)
-    # per-channel image mean within 1.5 % (16 spp reference noise dominates)
-    assert np.allclose(g.mean(axis=(0, 1)), r.mean(axis=(0, 1)), rtol=0.015), (g.mean(axis=(0, 1)), r.mean(axis=(0, 1)))
-    # 8x8 block means (625 blocks): 99 % within 15 % + small absolute floor
-    gb = g.reshape(25, 8, 25, 8, 3).mean(axis=(1, 3))
-    rb = r.reshape(25, 8, 25, 8, 3).mean(axis=(1, 3))
-    ok = np.abs(gb - rb) <= 0.15 * np.maximum(gb, rb) + 0.01
-    assert ok.mean() > 0.99, ok.mean()
-    # the directly visible light is 2 * Le = 1.2 in both, pixel (i=100, j=199 is ceiling; light seen at top centre)
-    lit_g, lit_r = np.isclose(gpu, 1.2, atol=1e-3).all(axis=2), np.isclose(gold, 1.2, atol=1e-3).all(axis=2)
-    assert lit_r.sum() > 50 and (lit_g & lit_r).sum() >= 0.9 * lit_r.sum()
+    w = h = 200
+    spp, nseed, clamp = 16, 8, 1.0
+    gold = np.minimum(np.load(os.path.join(GOLD, f"fb_{scene}_200x200x16.npy")) / spp, clamp)
+    sc = pt.Scene(scene_path(scene), w, h)
+    imgs = []
+    for seed in range(nseed):
+        r = pt.Renderer(sc, seed=seed)
+        imgs.append(np.minimum(r.render(spp) / spp, clamp))
+        r.close()
+    imgs = np.array(imgs)
+    # (1) per-channel image mean: |z| < 4 against the seed-to-seed spread
+    m = imgs.mean(axis=(1, 2))
+    z = (gold.mean(axis=(0, 1)) - m.mean(0)) / (m.std(0, ddof=1) * np.sqrt(1 + 1 / nseed))
+    assert (np.abs(z) < 4).all(), z
+    # (2) 8x8 block means (625 blocks x 3 channels): >= 95 % within 4 sigma, >= 97.5 % within 6 sigma
+    bl = imgs.reshape(nseed, 25, 8, 25, 8, 3).mean(axis=(2, 4))
+    rb = gold.reshape(25, 8, 25, 8, 3).mean(axis=(1, 3))
+    zb = np.abs(rb - bl.mean(0)) / (bl.std(0, ddof=1) * np.sqrt(1 + 1 / nseed) + 1e-4)
+    assert (zb < 4).mean() >= 0.95 and (zb < 6).mean() >= 0.975, ((zb < 4).mean(), (zb < 6).mean())
+    if scene == "cornell_box":
+        # the directly visible light is 2*Le = 1.2 in the reference (emission added twice), here clamped to 1
+        raw = np.load(os.path.join(GOLD, f"fb_{scene}_200x200x16.npy")) / spp
+        lit_r = np.isclose(raw, 1.2, atol=1e-3).all(axis=2)
+        r = pt.Renderer(sc, seed=0)
+        lit_g = np.isclose(r.render(spp) / spp, 1.2, atol=1e-3).all(axis=2)
+        r.close()
+        assert lit_r.sum() > 1000 and (lit_g & lit_r).sum() >= 0.98 * lit_r.sum()
 
 
 def test_async_protocol_and_errors():
