@@ -151,9 +151,10 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             from oracle import pt_oracle
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(avail, 16)   # one GPU's share of the host (the GPU box guideline), all of them used
             osc = pt_oracle.Scene.from_json(args.scene)
-            spp_cpu = 2
+            spp_cpu = 4
             cfg = pt_oracle.make_config(WIDTH, HEIGHT, spp_cpu)
             c0 = time.perf_counter()
             _, octr = osc.render_stream(cfg, seed=0, threads=cores)

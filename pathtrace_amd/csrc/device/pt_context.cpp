@@ -408,7 +408,6 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
     if (!c || !rects || n_rects < 1) { set_err("pt_render_tiles_async: bad argument"); return -1; }
     if (spp_begin < 0 || spp_end <= spp_begin) { set_err("pt_render_tiles_async: bad sample range [%d,%d)", spp_begin, spp_end); return -1; }
     HIP_TRY(hipSetDevice(c->device));
-    if (c->profiling) c->timed.clear();
     // rects -> bands of at most P pixels each
     std::vector<DTile> bands;
     std::vector<int> band_h;
