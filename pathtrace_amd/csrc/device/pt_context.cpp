@@ -118,13 +118,43 @@ static DRect make_rect(float x0, float z0, float x1, float z1, float y, int mat,
     return r;
 }
 
-// bvh_node tree -> sweep program (pt_device.h).  Returns the stack depth used, or -1.
-static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<DOp> &ops, int &max_depth)
+// bvh_node tree -> sweep program (pt_device.h).  `pending_push` is the slot the NEXT emitted op must push into.
+static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<DOp> &ops, int &max_depth, int &pending_push)
 {
     if (child < 0) {
+        const int ii = ~child;
+        const pt_instance &in = sc->instances[ii];
+        const pt_primitive &p = sc->primitives[in.primitive];
         DOp op{};
-        op.kind = OP_LEAF;
-        op.a = ~child;
+        op.a = ii;
+        op.id_base = ii * 8;
+        op.push_slot = pending_push;
+        pending_push = -1;
+        memcpy(op.f, in.inv, 12 * sizeof(float));
+        switch (p.type) {
+        case PT_PRIM_RECT:
+            op.kind = p.plane == PT_PLANE_XY ? OP_LEAF_RECT_XY : (p.plane == PT_PLANE_YZ ? OP_LEAF_RECT_YZ : OP_LEAF_RECT_XZ);
+            memcpy(op.f + 12, p.rect, 5 * sizeof(float));
+            break;
+        case PT_PRIM_BOX:
+            op.kind = OP_LEAF_BOX;
+            memcpy(op.f + 12, p.p0, 12); memcpy(op.f + 15, p.p1, 12);
+            break;
+        case PT_PRIM_SPHERE:
+            op.kind = OP_LEAF_SPHERE;
+            memcpy(op.f + 12, p.center, 12); op.f[15] = p.radius;
+            break;
+        case PT_PRIM_VOLUME: {
+            const pt_primitive &bd = sc->primitives[p.boundary];
+            if (bd.type == PT_PRIM_BOX) {
+                op.kind = OP_LEAF_VOLBOX;
+                memcpy(op.f + 12, bd.p0, 12); memcpy(op.f + 15, bd.p1, 12);
+                op.f[18] = p.density;
+            } else op.kind = OP_LEAF_GENERIC;
+            break;
+        }
+        default: return -1;
+        }
         ops.push_back(op);
         return 0;
     }
@@ -133,18 +163,18 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
     size_t me = ops.size();
     DOp en{};
     en.kind = OP_ENTER;
-    memcpy(en.box, n.bbox, sizeof en.box);
+    en.push_slot = pending_push;
+    pending_push = -1;
+    memcpy(en.f, n.bbox, 6 * sizeof(float));
     ops.push_back(en);
-    if (emit_ops(sc, n.left, depth, ops, max_depth)) return -1;
-    DOp pu{};
-    pu.kind = OP_PUSH;
-    pu.slot = depth;
-    ops.push_back(pu);
+    if (emit_ops(sc, n.left, depth, ops, max_depth, pending_push)) return -1;
+    pending_push = depth;   // the left result is parked in slot `depth` by whatever op starts eval(right)
     max_depth = std::max(max_depth, depth + 1);
-    if (emit_ops(sc, n.right, depth + 1, ops, max_depth)) return -1;
+    if (emit_ops(sc, n.right, depth + 1, ops, max_depth, pending_push)) return -1;
     DOp co{};
     co.kind = OP_COMBINE;
     co.slot = depth;
+    co.push_slot = -1;
     ops.push_back(co);
     ops[me].a = (int)ops.size();
     return 0;
@@ -235,17 +265,21 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
                 set_err("pt_create: bvh node %d: bad child %d (nodes must be in preorder)", i, ch);
                 return -1;
             }
-    if (emit_ops(sc, 0, 0, ops, max_depth)) { set_err("pt_create: malformed BVH"); return -1; }
+    int pending_push = -1;
+    if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) { set_err("pt_create: malformed BVH"); return -1; }
     if (max_depth > PT_MAX_STACK) {
         set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds %d", max_depth, PT_MAX_STACK);
         return -1;
     }
+    for (DOp &op : ops)
+        if (op.kind == OP_LEAF_VOLBOX) op.vol_ord = insts[op.a].vol_ordinal;
     DScene &S = c->S;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
         dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
         return -1;
     S.n_insts = (int)insts.size(); S.n_prims = (int)prims.size(); S.n_mats = (int)mats.size();
     S.n_ops = (int)ops.size(); S.n_lights = (int)lights.size(); S.n_vol = nvol;
+    S.stack_depth = std::max(max_depth, 1);
     const pt_camera &cm = sc->camera;
     memcpy(S.cam.origin, cm.origin, 12); memcpy(S.cam.llc, cm.lower_left_corner, 12);
     memcpy(S.cam.horizontal, cm.horizontal, 12); memcpy(S.cam.vertical, cm.vertical, 12);

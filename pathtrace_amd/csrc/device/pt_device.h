@@ -40,18 +40,33 @@ struct DMat {            // 32 bytes
 };
 // Traversal program: the pointer BVH (reference bvh.h:31-69) flattened into a linear op list that every
 // lane of a wave sweeps in lock step.  eval(node) = ENTER box-test (miss: result MISS, jump to `a`) ;
-// eval(left) ; PUSH slot ; eval(right) ; COMBINE slot   -- COMBINE keeps the reference's rule
-// "both hit: left iff left.t < right.t" (bvh.h:40-47), so exact-t ties and NaN t resolve identically.
-enum { OP_ENTER = 0, OP_LEAF = 1, OP_PUSH = 2, OP_COMBINE = 3 };
-struct DOp {             // 48 bytes
-    int32_t kind;
-    int32_t a;           // ENTER: pc to continue at when the box is missed;  LEAF: instance index
-    int32_t slot;        // PUSH / COMBINE: short-stack slot (static per op)
-    int32_t pad;
-    float box[6];        // ENTER: node bbox
-    int32_t pad2[2];
+// eval(left) ; [push result: folded into the next op as push_slot] ; eval(right) ; COMBINE slot.
+// COMBINE keeps the reference's rule "both hit: left iff left.t < right.t" (bvh.h:40-47), so exact-t ties and
+// NaN t resolve identically.  Every op carries the data it needs INLINE (node box, or the instance's inverse
+// affine + its primitive's parameters): one op = one 128-byte scalar load with an address that depends only on
+// the program counter, so loads are never chained (op -> instance -> primitive) and can be prefetched.
+enum {
+    OP_ENTER = 0,        // f[0..5] = node bbox; a = pc to continue at when the box is missed
+    OP_COMBINE = 1,      // slot
+    OP_LEAF_RECT_XY = 2, // f[0..11] = instance inverse affine, f[12..16] = x0 z0 x1 z1 y   (primitive.h:120-124)
+    OP_LEAF_RECT_XZ = 3,
+    OP_LEAF_RECT_YZ = 4,
+    OP_LEAF_BOX = 5,     // f[0..11] inverse, f[12..14] = p0, f[15..17] = p1              (primitive.h:229-242)
+    OP_LEAF_SPHERE = 6,  // f[0..11] inverse, f[12..14] = center, f[15] = radius
+    OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, vol_ord
+    OP_LEAF_GENERIC = 8, // anything else (volume with rect/sphere boundary): a = instance index, tables in DScene
 };
-#define PT_MAX_STACK 8   // short-stack slots per lane held in LDS (tree height <= 8)
+struct DOp {             // 128 bytes, 128-byte aligned in the device array
+    int32_t kind;
+    int32_t a;
+    int32_t slot;        // COMBINE: short-stack slot
+    int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
+    int32_t id_base;     // LEAF: instance_index * 8
+    int32_t vol_ord;     // LEAF_VOLBOX: ordinal among volume instances (stream RNG dimension slot)
+    int32_t pad[2];
+    float f[24];
+};
+#define PT_MAX_STACK 8   // short-stack slots per lane and ray held in LDS (tree height <= 8)
 
 struct DCamera {
     float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
@@ -65,6 +80,7 @@ struct DScene {
     const DOp *ops;
     const int32_t *lights;
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
+    int32_t stack_depth;         // short-stack slots the program uses
     DCamera cam;
     float bg[3];
     // config

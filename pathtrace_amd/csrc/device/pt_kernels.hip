@@ -268,49 +268,205 @@ DEVI bool aabb_hit(const float *box, v3 A, v3 inv, float tmin, float tmax)
     return ok;
 }
 
-DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, v3 B, uint32_t k0, uint32_t k1, uint32_t vol_dim_base,
-                    float2 *stk, float &out_t, int &out_id)
+// ---- leaf tests on NR rays that share one origin (NR = 1: extension ray; NR = light_samples: the shadow rays of
+// one hit).  The local origin (ray::apply ray.h:20-24) and every numerator that depends only on it are computed
+// once; each ray's own arithmetic is exactly the single-ray sequence.
+template <int PLANE>   // 0 XY, 1 XZ, 2 YZ: which local component is the plane axis / x / z (primitive.h:104-121)
+DEVI void rect_axes(v3 v, float &x, float &pl, float &z)
+{
+    if (PLANE == 0) { x = v.x; pl = v.z; z = v.y; }
+    else if (PLANE == 2) { x = v.y; pl = v.x; z = v.z; }
+    else { x = v.x; pl = v.y; z = v.z; }
+}
+template <int PLANE>
+DEVI bool rect_hit_axes(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float t0, float t1, float &t_out)
+{   // primitive.h:186-206 with the shuffle resolved at compile time; num = y - o.y
+    float dx, dpl, dz;
+    rect_axes<PLANE>(Bl, dx, dpl, dz);
+    const float t = num / dpl;
+    if (t < t0 || t > t1) return false;
+    const float xh = ox + t * dx;
+    const float zh = oz + t * dz;
+    if (xh < x0 || xh > x1 || zh < z0 || zh > z1) return false;
+    t_out = t;
+    return true;
+}
+DEVI bool box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t0, float t1, float &t_out, int &face)
+{   // box::hit -> hittable_list::hit over the six sides in primitive.h:232-240 order; closest_so_far shrinks and a
+    // later side with an equal t replaces (hittable_list.h:27-35)
+    bool any = false;
+    float closest = t1, t;
+    if (rect_hit_axes<0>(p0[0], p0[1], p1[0], p1[1], p0[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t)) { any = true; closest = t; face = 0; }
+    if (rect_hit_axes<0>(p0[0], p0[1], p1[0], p1[1], p1[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t)) { any = true; closest = t; face = 1; }
+    if (rect_hit_axes<2>(p0[1], p0[2], p1[1], p1[2], p0[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 2; }
+    if (rect_hit_axes<2>(p0[1], p0[2], p1[1], p1[2], p1[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 3; }
+    if (rect_hit_axes<1>(p0[0], p0[2], p1[0], p1[2], p0[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 4; }
+    if (rect_hit_axes<1>(p0[0], p0[2], p1[0], p1[2], p1[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 5; }
+    t_out = closest;
+    return any;
+}
+
+// ------------------------------------------------------------------------------------------------
+// World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep over NR rays per lane
+// that share the origin A.  Returns per ray id = -1 (miss) or instance*8 + face, and t.  `stk` points at this
+// lane's column of the LDS short stack, laid out [slot][ray][PT_BLOCK] float2.
+// ------------------------------------------------------------------------------------------------
+template <int NR>
+DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
+                      const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR])
 {
     const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
-    v3 inv = V(1.0f / B.x, 1.0f / B.y, 1.0f / B.z);
-    float cur_t = 0.0f;
-    int cur_id = -1;
-    int skip = lane_valid ? 0 : 0x7fffffff;
+    v3 inv[NR];
+    float cur_t[NR];
+    int cur_id[NR], skip[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        inv[r] = V(1.0f / B[r].x, 1.0f / B[r].y, 1.0f / B[r].z);   // aabb.h:38, same value at every node
+        cur_t[r] = 0.0f;
+        cur_id[r] = -1;
+        skip[r] = lane_valid ? 0 : 0x7fffffff;
+    }
     const int n_ops = S.n_ops;
     for (int pc = 0; pc < n_ops; ++pc) {
         const DOp &op = S.ops[pc];
-        const bool active = pc >= skip;
         const int kind = op.kind;
+        if (op.push_slot >= 0) {
+#pragma unroll
+            for (int r = 0; r < NR; r++)
+                if (pc >= skip[r]) stk[(op.push_slot * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
+        }
         if (kind == OP_ENTER) {
-            if (active && !aabb_hit(op.box, A, inv, T_MIN, T_MAX)) { cur_id = -1; skip = op.a; }
-        } else if (kind == OP_LEAF) {
-            const int ii = op.a;
-            const DInst &in = S.insts[ii];
-            const DPrim &pr = S.prims[in.prim];
-            if (active) {
-                v3 Al = xf_point(in.inv, A);        // ray::apply (ray.h:20-24)
-                v3 Bl = xf_linear(in.inv, B);
-                float t;
-                int face = 0;
-                bool hit;
-                if (pr.type == 3) hit = volume_hit_t(S, pr, Al, Bl, T_MIN, T_MAX, k0, k1, vol_dim_base + (uint32_t)in.vol_ordinal, t);
-                else hit = solid_hit_t(pr, Al, Bl, T_MIN, T_MAX, t, face);
-                cur_id = hit ? (ii * 8 + face) : -1;
-                cur_t = hit ? t : 0.0f;
+            // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays
+            const float dx0 = op.f[0] - A.x, dy0 = op.f[1] - A.y, dz0 = op.f[2] - A.z;
+            const float dx1 = op.f[3] - A.x, dy1 = op.f[4] - A.y, dz1 = op.f[5] - A.z;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float tmin = T_MIN, tmax = T_MAX;
+                bool ok = true;
+                {
+                    float t0 = dx0 * inv[r].x, t1 = dx1 * inv[r].x;
+                    if (inv[r].x < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+                    if (tmax <= tmin) ok = false;
+                }
+                {
+                    float t0 = dy0 * inv[r].y, t1 = dy1 * inv[r].y;
+                    if (inv[r].y < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+                    if (tmax <= tmin) ok = false;
+                }
+                {
+                    float t0 = dz0 * inv[r].z, t1 = dz1 * inv[r].z;
+                    if (inv[r].z < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
+                    if (tmax <= tmin) ok = false;
+                }
+                if (pc >= skip[r] && !ok) { cur_id[r] = -1; skip[r] = op.a; }
             }
-        } else if (kind == OP_PUSH) {
-            if (active) stk[op.slot * PT_BLOCK] = make_float2(cur_t, __int_as_float(cur_id));
-        } else {  // OP_COMBINE   (bvh.h:36-66)
-            if (active) {
-                float2 l = stk[op.slot * PT_BLOCK];
-                int lid = __float_as_int(l.y);
-                bool take_left = (lid >= 0) && ((cur_id < 0) || (l.x < cur_t));
-                if (take_left) { cur_t = l.x; cur_id = lid; }
+        } else if (kind == OP_COMBINE) {   // bvh.h:36-66
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (pc >= skip[r]) {
+                    const float2 l = stk[(op.slot * NR + r) * PT_BLOCK];
+                    const int lid = __float_as_int(l.y);
+                    const bool take_left = (lid >= 0) && ((cur_id[r] < 0) || (l.x < cur_t[r]));
+                    if (take_left) { cur_t[r] = l.x; cur_id[r] = lid; }
+                }
+            }
+        } else if (kind == OP_LEAF_GENERIC) {
+            const DInst &in = S.insts[op.a];
+            const DPrim &pr = S.prims[in.prim];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if (pc >= skip[r]) {
+                    const v3 Al = xf_point(in.inv, A);
+                    const v3 Bl = xf_linear(in.inv, B[r]);
+                    float t;
+                    int face = 0;
+                    bool hit;
+                    if (pr.type == 3) hit = volume_hit_t(S, pr, Al, Bl, T_MIN, T_MAX, k0, k1, vol_dim_base[r] + (uint32_t)in.vol_ordinal, t);
+                    else hit = solid_hit_t(pr, Al, Bl, T_MIN, T_MAX, t, face);
+                    cur_id[r] = hit ? (op.id_base + face) : -1;
+                    cur_t[r] = hit ? t : 0.0f;
+                }
+            }
+        } else {
+            // instance::hit primitive.h:298-312: local origin once, local direction per ray
+            const v3 Al = xf_point(op.f, A);
+            if (kind == OP_LEAF_BOX) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = xf_linear(op.f, B[r]);
+                    float t;
+                    int face = 0;
+                    const bool hit = box_hit_shared(op.f + 12, op.f + 15, Al, Bl, T_MIN, T_MAX, t, face);
+                    if (pc >= skip[r]) { cur_id[r] = hit ? (op.id_base + face) : -1; cur_t[r] = hit ? t : 0.0f; }
+                }
+            } else if (kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = xf_linear(op.f, B[r]);
+                    bool hit = false;
+                    float t = 0.0f, t1v, t2v;
+                    int f;
+                    if (box_hit_shared(op.f + 12, op.f + 15, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f)) {
+                        if (box_hit_shared(op.f + 12, op.f + 15, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
+                            if (t1v < T_MIN) t1v = T_MIN;
+                            if (t2v > T_MAX) t2v = T_MAX;
+                            if (!(t1v >= t2v)) {
+                                if (t1v < 0) t1v = 0;
+                                const float dlen = vlen(Bl);
+                                const float distance_inside = (t2v - t1v) * dlen;
+                                const float u = (float)rnd(k0, k1, vol_dim_base[r] + (uint32_t)op.vol_ord);
+                                const float hit_distance = (-(1 / op.f[18])) * ptm_logf(u);
+                                if (hit_distance < distance_inside) { t = t1v + hit_distance / dlen; hit = true; }
+                            }
+                        }
+                    }
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                }
+            } else if (kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95
+                const v3 oc = vsub(Al, V(op.f[12], op.f[13], op.f[14]));
+                const float c = vdot(oc, oc) - op.f[15] * op.f[15];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = xf_linear(op.f, B[r]);
+                    const float a = vdot(Bl, Bl);
+                    const float b = vdot(oc, Bl);
+                    const float disc = b * b - a * c;
+                    bool hit = false;
+                    float t = 0.0f;
+                    if (disc > 0) {
+                        float temp = (-b - sqrtf(disc)) / a;
+                        if (temp < T_MAX && temp > T_MIN) { t = temp; hit = true; }
+                        else {
+                            temp = (-b + sqrtf(disc)) / a;
+                            if (temp < T_MAX && temp > T_MIN) { t = temp; hit = true; }
+                        }
+                    }
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                }
+            } else {   // the three rect alignments (rect::hit primitive.h:186-225)
+                float ox, opl, oz;
+                if (kind == OP_LEAF_RECT_XY) rect_axes<0>(Al, ox, opl, oz);
+                else if (kind == OP_LEAF_RECT_YZ) rect_axes<2>(Al, ox, opl, oz);
+                else rect_axes<1>(Al, ox, opl, oz);
+                const float num = op.f[16] - opl;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = xf_linear(op.f, B[r]);
+                    float t = 0.0f;
+                    bool hit;
+                    if (kind == OP_LEAF_RECT_XY) hit = rect_hit_axes<0>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else if (kind == OP_LEAF_RECT_YZ) hit = rect_hit_axes<2>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else hit = rect_hit_axes<1>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                }
             }
         }
     }
-    out_t = cur_t;
-    out_id = cur_id;
+#pragma unroll
+    for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
 }
 
 // hit_record of the winning primitive: rec.p, rec.normal, rec.mat_ptr  (primitive.h:186-225, 298-312; volume.h:77-88)
@@ -568,7 +724,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, DStreams st, DBatch b, int qi, int bounce)
 {
-    __shared__ float2 stack[PT_MAX_STACK * PT_BLOCK];
+    extern __shared__ float2 stack[];   // [stack_depth][1][PT_BLOCK]
     const int seg = blockIdx.x;
     const DQueue q = st.q[qi];
     const int n = q.count[seg];
@@ -585,10 +741,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, DStreams st, DBat
         float4 r0 = q.r0[pos], r1 = q.r1[pos];
         uint32_t k0 = 0, k1 = 0;
         if (has_vol) { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
-        float t;
-        int id;
-        world_hit(S, valid, V(r0.x, r0.y, r0.z), V(r1.x, r1.y, r1.z), k0, k1, base_dim, &stack[threadIdx.x], t, id);
-        if (valid) st.hit[pos] = make_float2(t, __int_as_float(id));
+        float t[1];
+        int id[1];
+        const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
+        const uint32_t vd[1] = {base_dim};
+        world_hit_n<1>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
+        if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0) {
         atomicAdd(&st.counters->rays, (unsigned long long)n);
@@ -766,9 +924,30 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, DStreams st, DBatc
 // whatever was hit, NaN contributions dropped, sum += light_contribution / light_samples,
 // then the deferred second emitter addition.
 // ------------------------------------------------------------------------------------------------
+// emitted() of whatever a shadow ray hit, times the stored coefficient (integrator.h:252-262)
+DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id, v3 coef, float pick_pdf, v3 &lc)
+{
+    if (id < 0) return;
+    const int ii = id >> 3, face = id & 7;
+    const DInst &in = S.insts[ii];
+    const DPrim &pr = S.prims[in.prim];
+    const DMat m = S.mats[pr.hit_mat[face]];
+    v3 le = V(0.0f, 0.0f, 0.0f);
+    if (m.type == 3) {
+        if (m.two_sided) le = vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
+        else le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
+    }
+    v3 c = vmul(coef, le);
+    c = vdivf(c, pick_pdf);
+    if (!v_is_nan(c)) lc = vadd(lc, c);
+}
+
+// NR = light_samples when it is 1, 2 or 4 (the rays of one hit share their origin and are traversed together),
+// NR = 0: any other count, one ray at a time.
+template <int NR>
 __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBatch b, int bounce)
 {
-    __shared__ float2 stack[PT_MAX_STACK * PT_BLOCK];
+    extern __shared__ float2 stack[];   // [stack_depth][max(NR,1)][PT_BLOCK]
     const int seg = blockIdx.x;
     const DShadowQueue sq = st.sq;
     const int n = sq.count[seg];
@@ -790,26 +969,35 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBa
         uint32_t k0 = 0, k1 = 0;
         if (NV) { const uint2 kk = sq.key[pos]; k0 = kk.x; k1 = kk.y; }
         v3 lc = V(0.0f, 0.0f, 0.0f);
-        for (uint32_t k = 0; k < L; k++) {
-            const float4 d = sq.d[(long long)k * P + pos];
-            const float2 e = sq.e[(long long)k * P + pos];
-            const v3 ldir = V(d.x, d.y, d.z);
-            float t;
-            int id;
-            world_hit(S, valid, hp, ldir, k0, k1, base + NV + k * (3u + NV) + 3u, &stack[threadIdx.x], t, id);
-            if (valid && id >= 0) {
-                const int ii = id >> 3, face = id & 7;
-                const DInst &in = S.insts[ii];
-                const DPrim &pr = S.prims[in.prim];
-                const DMat m = S.mats[pr.hit_mat[face]];
-                v3 le = V(0.0f, 0.0f, 0.0f);
-                if (m.type == 3) {
-                    if (m.two_sided) le = vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
-                    else le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
-                }
-                v3 c = vmul(V(d.w, e.x, e.y), le);
-                c = vdivf(c, pick_pdf);
-                if (!v_is_nan(c)) lc = vadd(lc, c);
+        if (NR > 0) {
+            constexpr int R = NR > 0 ? NR : 1;
+            v3 ldir[R], coef[R];
+            uint32_t vd[R];
+            float t[R];
+            int id[R];
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                const float4 d = sq.d[(long long)k * P + pos];
+                const float2 e = sq.e[(long long)k * P + pos];
+                ldir[k] = V(d.x, d.y, d.z);
+                coef[k] = V(d.w, e.x, e.y);
+                vd[k] = base + NV + (uint32_t)k * (3u + NV) + 3u;
+            }
+            world_hit_n<R>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < R; k++) connect_contribution(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
+            }
+        } else {
+            for (uint32_t k = 0; k < L; k++) {
+                const float4 d = sq.d[(long long)k * P + pos];
+                const float2 e = sq.e[(long long)k * P + pos];
+                const v3 ldir[1] = {V(d.x, d.y, d.z)};
+                const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
+                float t[1];
+                int id[1];
+                world_hit_n<1>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                if (valid) connect_contribution(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
         if (valid) {
@@ -857,7 +1045,8 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 }
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, qi, bounce);
+    const size_t lds = (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
+    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, qi, bounce);
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
@@ -865,7 +1054,13 @@ void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, 
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_connect, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, bounce);
+    const int L = S.light_samples;
+    const int nr = (L == 1 || L == 2 || L == 4) ? L : 0;
+    const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
+    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
+    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
+    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
+    else hipLaunchKernelGGL(k_connect<0>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
