@@ -150,7 +150,7 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
                 op.kind = OP_LEAF_VOLBOX;
                 memcpy(op.f + 12, bd.p0, 12); memcpy(op.f + 15, bd.p1, 12);
                 op.f[18] = p.density;
-            } else op.kind = OP_LEAF_GENERIC;
+            } else return -2;   // only box boundaries (the reference's volume scenes); refused loudly by the caller
             break;
         }
         default: return -1;
@@ -266,14 +266,29 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
                 return -1;
             }
     int pending_push = -1;
-    if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) { set_err("pt_create: malformed BVH"); return -1; }
+    if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) {
+        set_err("pt_create: malformed BVH, or a volume whose boundary is not a box (only box boundaries are implemented "
+                "on the device: the reference's volume scenes use nothing else)");
+        return -1;
+    }
     if (max_depth > PT_MAX_STACK) {
         set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds %d", max_depth, PT_MAX_STACK);
         return -1;
     }
     for (DOp &op : ops)
         if (op.kind == OP_LEAF_VOLBOX) op.vol_ord = insts[op.a].vol_ordinal;
+    // emitted radiance by hit id (instance*8 + face): power * emit->value * emit->alpha (material.h:219), the same two
+    // float multiplications the kernels would do (this file is compiled with -ffp-contract=off)
+    std::vector<float4> emit((size_t)sc->n_instances * 8, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int i = 0; i < sc->n_instances; i++)
+        for (int f = 0; f < 8; f++) {
+            const DMat &m = mats[prims[insts[i].prim].hit_mat[f]];
+            if (m.type != PT_MAT_DIFFUSE_LIGHT) continue;
+            const float pr = m.power * m.r, pg = m.power * m.g, pb = m.power * m.b;
+            emit[(size_t)i * 8 + f] = make_float4(m.alpha * pr, m.alpha * pg, m.alpha * pb, m.two_sided ? 0.f : 1.f);
+        }
     DScene &S = c->S;
+    if (dev_upload(c, &S.emit, emit)) return -1;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
         dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
         return -1;

@@ -54,7 +54,6 @@ enum {
     OP_LEAF_BOX = 5,     // f[0..11] inverse, f[12..14] = p0, f[15..17] = p1              (primitive.h:229-242)
     OP_LEAF_SPHERE = 6,  // f[0..11] inverse, f[12..14] = center, f[15] = radius
     OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, vol_ord
-    OP_LEAF_GENERIC = 8, // anything else (volume with rect/sphere boundary): a = instance index, tables in DScene
 };
 struct DOp {             // 128 bytes, 128-byte aligned in the device array
     int32_t kind;
@@ -79,6 +78,8 @@ struct DScene {
     const DMat *mats;
     const DOp *ops;
     const int32_t *lights;
+    const float4 *emit;          // [n_insts*8] by hit id: emitted radiance of that face's material (xyz), w = 1 if it
+                                 // is a one-sided diffuse_light (needs the facing test of material.h:214-216), else 0
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
     int32_t stack_depth;         // short-stack slots the program uses
     DCamera cam;

@@ -37,6 +37,7 @@ namespace ptd {
 // vec3 (reference vec3.h:11-199); same association as the C++ operators
 // ------------------------------------------------------------------------------------------------
 struct v3 { float x, y, z; };
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define DEVI __device__ __forceinline__
 DEVI v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
 DEVI v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -174,22 +175,6 @@ DEVI v3 rect_normal(const DRect &q, v3 B)
     if (vdot(B, n) > 0) n = vneg(n);
     return n;
 }
-DEVI bool box_hit_t(const DPrim &p, v3 A, v3 B, float t0, float t1, float &t_out, int &face)
-{   // primitive.h:243-246 -> hittable_list.h:21-38 (closest_so_far shrinks; a later equal t replaces)
-    bool any = false;
-    float closest = t1;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        float t;
-        if (rect_hit_t(p.r[i], A, B, t0, closest, t)) {
-            any = true;
-            closest = t;
-            face = i;
-        }
-    }
-    t_out = closest;
-    return any;
-}
 DEVI bool sphere_hit_t(const DPrim &s, v3 A, v3 B, float t_min, float t_max, float &t_out)
 {   // primitive.h:64-95
     v3 oc = vsub(A, V(s.cx, s.cy, s.cz));
@@ -205,69 +190,6 @@ DEVI bool sphere_hit_t(const DPrim &s, v3 A, v3 B, float t_min, float t_max, flo
     }
     return false;
 }
-// rect / box / sphere by (wave-uniform) type
-DEVI bool solid_hit_t(const DPrim &p, v3 A, v3 B, float t0, float t1, float &t_out, int &face)
-{
-    face = 0;
-    if (p.type == 0) return rect_hit_t(p.r[0], A, B, t0, t1, t_out);
-    if (p.type == 1) return box_hit_t(p, A, B, t0, t1, t_out, face);
-    if (p.type == 2) return sphere_hit_t(p, A, B, t0, t1, t_out);
-    return false;
-}
-DEVI bool volume_hit_t(const DScene &S, const DPrim &p, v3 A, v3 B, float t_min, float t_max, uint32_t k0, uint32_t k1,
-                       uint32_t dim, float &t_out)
-{   // volume.h:29-93
-    const DPrim &b = S.prims[p.boundary];
-    float t1v, t2v;
-    int f;
-    if (solid_hit_t(b, A, B, -FLT_MAX, FLT_MAX, t1v, f)) {
-        if (solid_hit_t(b, A, B, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
-            if (t1v < t_min) t1v = t_min;
-            if (t2v > t_max) t2v = t_max;
-            if (t1v >= t2v) return false;
-            if (t1v < 0) t1v = 0;
-            float dlen = vlen(B);
-            float distance_inside = (t2v - t1v) * dlen;
-            float u = (float)rnd(k0, k1, dim);
-            float hit_distance = (-(1 / p.density)) * ptm_logf(u);
-            if (hit_distance < distance_inside) {
-                t_out = t1v + hit_distance / dlen;
-                return true;
-            }
-        }
-    }
-    return false;
-}
-
-// ------------------------------------------------------------------------------------------------
-// World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep.
-// Returns id = -1 (miss) or instance*8 + face, and t.   `stk` points at this lane's column of the LDS
-// short stack ([slot][PT_BLOCK] float2).
-// ------------------------------------------------------------------------------------------------
-DEVI bool aabb_hit(const float *box, v3 A, v3 inv, float tmin, float tmax)
-{   // aabb.h:34-53 with invD hoisted (same value for every node of one ray)
-    bool ok = true;
-    {
-        float t0 = (box[0] - A.x) * inv.x, t1 = (box[3] - A.x) * inv.x;
-        if (inv.x < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) ok = false;
-    }
-    {
-        float t0 = (box[1] - A.y) * inv.y, t1 = (box[4] - A.y) * inv.y;
-        if (inv.y < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) ok = false;
-    }
-    {
-        float t0 = (box[2] - A.z) * inv.z, t1 = (box[5] - A.z) * inv.z;
-        if (inv.z < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-        tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-        if (tmax <= tmin) ok = false;
-    }
-    return ok;
-}
-
 // ---- leaf tests on NR rays that share one origin (NR = 1: extension ray; NR = light_samples: the shadow rays of
 // one hit).  The local origin (ray::apply ray.h:20-24) and every numerator that depends only on it are computed
 // once; each ray's own arithmetic is exactly the single-ray sequence.
@@ -328,17 +250,20 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
     }
     const int n_ops = S.n_ops;
     for (int pc = 0; pc < n_ops; ++pc) {
-        const DOp &op = S.ops[pc];
-        const int kind = op.kind;
-        if (op.push_slot >= 0) {
+        // one op = two 64-byte scalar loads (s_load_dwordx16) whose address depends only on pc
+        const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc]);
+        const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&S.ops[pc]) + 1);
+        const int kind = w0[0], op_a = w0[1], op_slot = w0[2], op_push = w0[3], op_id_base = w0[4], op_vol_ord = w0[5];
+#define OPF(i) __int_as_float((i) < 8 ? w0[8 + (i)] : w1[(i) - 8])
+        if (op_push >= 0) {
 #pragma unroll
             for (int r = 0; r < NR; r++)
-                if (pc >= skip[r]) stk[(op.push_slot * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
+                if (pc >= skip[r]) stk[(op_push * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
         }
         if (kind == OP_ENTER) {
             // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays
-            const float dx0 = op.f[0] - A.x, dy0 = op.f[1] - A.y, dz0 = op.f[2] - A.z;
-            const float dx1 = op.f[3] - A.x, dy1 = op.f[4] - A.y, dz1 = op.f[5] - A.z;
+            const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
+            const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 float tmin = T_MIN, tmax = T_MAX;
@@ -361,76 +286,61 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
                     if (tmax <= tmin) ok = false;
                 }
-                if (pc >= skip[r] && !ok) { cur_id[r] = -1; skip[r] = op.a; }
+                if (pc >= skip[r] && !ok) { cur_id[r] = -1; skip[r] = op_a; }
             }
         } else if (kind == OP_COMBINE) {   // bvh.h:36-66
 #pragma unroll
             for (int r = 0; r < NR; r++) {
                 if (pc >= skip[r]) {
-                    const float2 l = stk[(op.slot * NR + r) * PT_BLOCK];
+                    const float2 l = stk[(op_slot * NR + r) * PT_BLOCK];
                     const int lid = __float_as_int(l.y);
                     const bool take_left = (lid >= 0) && ((cur_id[r] < 0) || (l.x < cur_t[r]));
                     if (take_left) { cur_t[r] = l.x; cur_id[r] = lid; }
                 }
             }
-        } else if (kind == OP_LEAF_GENERIC) {
-            const DInst &in = S.insts[op.a];
-            const DPrim &pr = S.prims[in.prim];
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                if (pc >= skip[r]) {
-                    const v3 Al = xf_point(in.inv, A);
-                    const v3 Bl = xf_linear(in.inv, B[r]);
-                    float t;
-                    int face = 0;
-                    bool hit;
-                    if (pr.type == 3) hit = volume_hit_t(S, pr, Al, Bl, T_MIN, T_MAX, k0, k1, vol_dim_base[r] + (uint32_t)in.vol_ordinal, t);
-                    else hit = solid_hit_t(pr, Al, Bl, T_MIN, T_MAX, t, face);
-                    cur_id[r] = hit ? (op.id_base + face) : -1;
-                    cur_t[r] = hit ? t : 0.0f;
-                }
-            }
         } else {
             // instance::hit primitive.h:298-312: local origin once, local direction per ray
-            const v3 Al = xf_point(op.f, A);
+            const float m[12] = {OPF(0), OPF(1), OPF(2), OPF(3), OPF(4), OPF(5), OPF(6), OPF(7), OPF(8), OPF(9), OPF(10), OPF(11)};
+            const float q0[3] = {OPF(12), OPF(13), OPF(14)}, q1[3] = {OPF(15), OPF(16), OPF(17)};
+            const v3 Al = xf_point(m, A);
             if (kind == OP_LEAF_BOX) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(op.f, B[r]);
+                    const v3 Bl = xf_linear(m, B[r]);
                     float t;
                     int face = 0;
-                    const bool hit = box_hit_shared(op.f + 12, op.f + 15, Al, Bl, T_MIN, T_MAX, t, face);
-                    if (pc >= skip[r]) { cur_id[r] = hit ? (op.id_base + face) : -1; cur_t[r] = hit ? t : 0.0f; }
+                    const bool hit = box_hit_shared(q0, q1, Al, Bl, T_MIN, T_MAX, t, face);
+                    if (pc >= skip[r]) { cur_id[r] = hit ? (op_id_base + face) : -1; cur_t[r] = hit ? t : 0.0f; }
                 }
             } else if (kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(op.f, B[r]);
+                    const v3 Bl = xf_linear(m, B[r]);
                     bool hit = false;
                     float t = 0.0f, t1v, t2v;
                     int f;
-                    if (box_hit_shared(op.f + 12, op.f + 15, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f)) {
-                        if (box_hit_shared(op.f + 12, op.f + 15, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
+                    if (box_hit_shared(q0, q1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f)) {
+                        if (box_hit_shared(q0, q1, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
                             if (t1v < T_MIN) t1v = T_MIN;
                             if (t2v > T_MAX) t2v = T_MAX;
                             if (!(t1v >= t2v)) {
                                 if (t1v < 0) t1v = 0;
                                 const float dlen = vlen(Bl);
                                 const float distance_inside = (t2v - t1v) * dlen;
-                                const float u = (float)rnd(k0, k1, vol_dim_base[r] + (uint32_t)op.vol_ord);
-                                const float hit_distance = (-(1 / op.f[18])) * ptm_logf(u);
+                                const float u = (float)rnd(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
+                                const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
                                 if (hit_distance < distance_inside) { t = t1v + hit_distance / dlen; hit = true; }
                             }
                         }
                     }
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
                 }
             } else if (kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95
-                const v3 oc = vsub(Al, V(op.f[12], op.f[13], op.f[14]));
-                const float c = vdot(oc, oc) - op.f[15] * op.f[15];
+                const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+                const float c = vdot(oc, oc) - q1[0] * q1[0];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(op.f, B[r]);
+                    const v3 Bl = xf_linear(m, B[r]);
                     const float a = vdot(Bl, Bl);
                     const float b = vdot(oc, Bl);
                     const float disc = b * b - a * c;
@@ -444,27 +354,28 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                             if (temp < T_MAX && temp > T_MIN) { t = temp; hit = true; }
                         }
                     }
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
                 }
             } else {   // the three rect alignments (rect::hit primitive.h:186-225)
                 float ox, opl, oz;
                 if (kind == OP_LEAF_RECT_XY) rect_axes<0>(Al, ox, opl, oz);
                 else if (kind == OP_LEAF_RECT_YZ) rect_axes<2>(Al, ox, opl, oz);
                 else rect_axes<1>(Al, ox, opl, oz);
-                const float num = op.f[16] - opl;
+                const float num = q1[1] - opl;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(op.f, B[r]);
+                    const v3 Bl = xf_linear(m, B[r]);
                     float t = 0.0f;
                     bool hit;
-                    if (kind == OP_LEAF_RECT_XY) hit = rect_hit_axes<0>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else if (kind == OP_LEAF_RECT_YZ) hit = rect_hit_axes<2>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else hit = rect_hit_axes<1>(op.f[12], op.f[13], op.f[14], op.f[15], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op.id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    if (kind == OP_LEAF_RECT_XY) hit = rect_hit_axes<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else if (kind == OP_LEAF_RECT_YZ) hit = rect_hit_axes<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else hit = rect_hit_axes<1>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
                 }
             }
         }
     }
+#undef OPF
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
 }
@@ -722,8 +633,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of every live path's ray (integrator.h:192-193)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, DStreams st, DBatch b, int qi, int bounce)
+__global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+        const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
+    // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
+    // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
+    S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][1][PT_BLOCK]
     const int seg = blockIdx.x;
     const DQueue q = st.q[qi];
@@ -759,8 +674,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, DStreams st, DBat
 // material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
 // continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, DStreams st, DBatch b, int qi, int bounce)
+__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+        const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
+    // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
+    // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
+    S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     __shared__ int sh4[PT_BLOCK / 64];
     __shared__ unsigned int sh_ctr[C_N];
     const int seg = blockIdx.x;
@@ -924,19 +843,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, DStreams st, DBatc
 // whatever was hit, NaN contributions dropped, sum += light_contribution / light_samples,
 // then the deferred second emitter addition.
 // ------------------------------------------------------------------------------------------------
-// emitted() of whatever a shadow ray hit, times the stored coefficient (integrator.h:252-262)
+// emitted() of whatever a shadow ray hit, times the stored coefficient (integrator.h:252-262).  The emitted radiance
+// comes from one table load by hit id; non-emitters contribute (coef*0)/pick = +-0 or NaN, i.e. nothing.
 DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id, v3 coef, float pick_pdf, v3 &lc)
 {
     if (id < 0) return;
-    const int ii = id >> 3, face = id & 7;
-    const DInst &in = S.insts[ii];
-    const DPrim &pr = S.prims[in.prim];
-    const DMat m = S.mats[pr.hit_mat[face]];
-    v3 le = V(0.0f, 0.0f, 0.0f);
-    if (m.type == 3) {
-        if (m.two_sided) le = vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
-        else le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
+    const float4 e = S.emit[id];
+    v3 le = V(e.x, e.y, e.z);
+    if (e.w != 0.0f) {   // one-sided light: material.h:214-228
+        const DMat m = S.mats[S.prims[S.insts[id >> 3].prim].hit_mat[id & 7]];
+        le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
     }
+    if (le.x == 0.0f && le.y == 0.0f && le.z == 0.0f) return;
     v3 c = vmul(coef, le);
     c = vdivf(c, pick_pdf);
     if (!v_is_nan(c)) lc = vadd(lc, c);
@@ -945,8 +863,12 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 // NR = light_samples when it is 1, 2 or 4 (the rays of one hit share their origin and are traversed together),
 // NR = 0: any other count, one ray at a time.
 template <int NR>
-__global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, DStreams st, DBatch b, int bounce)
+__global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+        const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
+    // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
+    // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
+    S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][max(NR,1)][PT_BLOCK]
     const int seg = blockIdx.x;
     const DShadowQueue sq = st.sq;
@@ -1046,21 +968,21 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const size_t lds = (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, qi, bounce);
+    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shade, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b, qi, bounce);
+    hipLaunchKernelGGL(k_shade, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
     const int L = S.light_samples;
     const int nr = (L == 1 || L == 2 || L == 4) ? L : 0;
     const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
-    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
-    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
-    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
-    else hipLaunchKernelGGL(k_connect<0>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, st, b, bounce);
+    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else hipLaunchKernelGGL(k_connect<0>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
