@@ -73,6 +73,9 @@ DEVI uint32_t stream_u32(uint32_t k0, uint32_t k1, uint32_t dim)
     return x;
 }
 DEVI double rnd(uint32_t k0, uint32_t k1, uint32_t dim) { return (double)stream_u32(k0, k1, dim) * (1.0 / 4294967296.0); }
+// float(rnd(...)): the 32-bit integer is rounded to 24 bits exactly once on either route and the scaling by 2^-32
+// is exact, so this equals the double route bit for bit without touching the f64 pipe
+DEVI float rndf(uint32_t k0, uint32_t k1, uint32_t dim) { return (float)stream_u32(k0, k1, dim) * 2.3283064365386963e-10f; }
 
 DEVI void ptm_sincos_2pi(float r, float &s, float &c)
 {
@@ -288,6 +291,12 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 }
                 if (pc >= skip[r] && !ok) { cur_id[r] = -1; skip[r] = op_a; }
             }
+            // no lane of the wave is inside this subtree any more (lanes masked by an enclosing miss resume at or
+            // after op_a as well): jump to the end of the subtree -- wave-uniform, costs one ballot
+            bool any_in = false;
+#pragma unroll
+            for (int r = 0; r < NR; r++) any_in |= (pc >= skip[r]);
+            if (!__any(any_in)) pc = op_a - 1;
         } else if (kind == OP_COMBINE) {   // bvh.h:36-66
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -327,7 +336,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                                 if (t1v < 0) t1v = 0;
                                 const float dlen = vlen(Bl);
                                 const float distance_inside = (t2v - t1v) * dlen;
-                                const float u = (float)rnd(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
+                                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
                                 const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
                                 if (hit_distance < distance_inside) { t = t1v + hit_distance / dlen; hit = true; }
                             }
@@ -464,8 +473,8 @@ DEVI v3 prim_random(const DPrim &p, v3 o, uint32_t k0, uint32_t k1, uint32_t dim
         v3 direction = vsub(V(p.cx, p.cy, p.cz), o);
         float d2 = vsqlen(direction);
         Onb uvw = onb_from_w(direction);
-        float r1 = (float)rnd(k0, k1, dim + 0);
-        float r2 = (float)rnd(k0, k1, dim + 1);
+        float r1 = rndf(k0, k1, dim + 0);
+        float r2 = rndf(k0, k1, dim + 1);
         float z = 1 + r2 * (sqrtf(1 - p.radius * p.radius / d2) - 1);
         float s, c;
         ptm_sincos_2pi(r1, s, c);
@@ -489,7 +498,16 @@ DEVI float power_heuristic(float fPdf, float gPdf)
 DEVI float cosine_pdf_value(v3 normal, v3 direction)
 {   // pdf.h:18-29
     float cosine = vdot(vunit(direction), vunit(normal));
-    if (cosine > 0) return (float)((double)cosine / PT_PI_D);
+    if (cosine > 0) {
+        // The reference computes (float)((double)cosine / M_PI).  q = cosine * RN(1/pi) is within 3 ulp(double) of
+        // d = RN(cosine / pi), so (float)q == (float)d unless a float rounding boundary (low 29 mantissa bits =
+        // 0x10000000) lies within a few double ulps of q; only then (about 1 call in 10^7), or when the result could be
+        // a float denormal, pay for the IEEE double division.
+        const double q = (double)cosine * 0.31830988618379067154;
+        const unsigned lo = (unsigned)__double2loint(q) & 0x1fffffffu;
+        if (lo - 0x0ffffff0u <= 0x20u || !(cosine > 1e-30f)) return (float)((double)cosine / PT_PI_D);
+        return (float)q;
+    }
     return 0.0f;
 }
 DEVI float material_value(int type, v3 normal, v3 direction)
@@ -501,19 +519,19 @@ DEVI float material_value(int type, v3 normal, v3 direction)
 DEVI v3 random_in_unit_sphere(uint32_t k0, uint32_t k1, uint32_t dim)
 {   // random.h:17-24 with cos(acos(x)) = x
     float su, cu;
-    ptm_sincos_2pi((float)rnd(k0, k1, dim + 0), su, cu);
+    ptm_sincos_2pi(rndf(k0, k1, dim + 0), su, cu);
     float cv = (float)(2 * rnd(k0, k1, dim + 1) - 1);
     float sv2 = 1.0f - cv * cv;
     float sv = sqrtf(sv2 > 0.0f ? sv2 : 0.0f);
-    float w = ptm_cbrtf((float)rnd(k0, k1, dim + 2));
+    float w = ptm_cbrtf(rndf(k0, k1, dim + 2));
     return V(cu * sv * w, cv * w, su * sv * w);
 }
 DEVI v3 material_generate(int type, v3 normal, uint32_t k0, uint32_t k1, uint32_t dim)
 {
     if (type == 0 || type == 1) {   // cosine_pdf::generate pdf.h:30-33, random.h:36-44
         Onb uvw = onb_from_w(normal);
-        float r1 = (float)rnd(k0, k1, dim + 0);
-        float r2 = (float)rnd(k0, k1, dim + 1);
+        float r1 = rndf(k0, k1, dim + 0);
+        float r2 = rndf(k0, k1, dim + 1);
         float z = sqrtf(1 - r2);
         float s, c;
         ptm_sincos_2pi(r1, s, c);
@@ -607,8 +625,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
         v3 offset = V(0.0f, 0.0f, 0.0f);
         if (S.cam.lens_radius != 0.0f) {   // random_in_unit_disk random.h:27-34
             float su, cu2;
-            ptm_sincos_2pi((float)rnd(k0, k1, DIM_LENS), su, cu2);
-            float rv = sqrtf((float)rnd(k0, k1, DIM_LENS + 1));
+            ptm_sincos_2pi(rndf(k0, k1, DIM_LENS), su, cu2);
+            float rv = sqrtf(rndf(k0, k1, DIM_LENS + 1));
             v3 rd = vscale(S.cam.lens_radius, V(cu2 * rv, su * rv, 0.0f));
             offset = vadd(vscale(rd.x, cu), vscale(rd.y, cv));
         }
@@ -809,10 +827,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
             if (NV) sq.key[o] = make_uint2(k0, k1);
             const bool att_ok = (double)vlen(att) > 0.0001;   // integrator.h:248
             const v3 ab = vmul(att, beta);
-            for (uint32_t k = 0; k < L; k++) {
-                const uint32_t kb = base + NV + k * (3u + NV);
-                const int idx = (int)(rnd(k0, k1, kb + 0) * (double)S.n_lights);   // world.h:31-35
-                const int light = S.lights[idx];
+            // one light (the common case): its index is wave-uniform, so its instance/primitive records are scalar
+            // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
+            auto light_sample = [&](const uint32_t k, const uint32_t kb, const int light) {
                 const v3 ldir = instance_random(S, light, hp, k0, k1, kb + 1);
                 const float cos_l = vdot(vunit(ldir), vunit(hn));
                 const float light_pdf_l = instance_pdf_value(S, light, hp, ldir);
@@ -826,6 +843,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
                 if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
                 sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                 sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+            };
+            if (S.n_lights == 1) {
+                const int light = S.lights[0];
+                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), light);
+            } else {
+                for (uint32_t k = 0; k < L; k++) {
+                    const uint32_t kb = base + NV + k * (3u + NV);
+                    const int idx = (int)(rnd(k0, k1, kb + 0) * (double)S.n_lights);   // world.h:31-35
+                    light_sample(k, kb, S.lights[idx]);
+                }
             }
         }
         out_n += tot_c;
