@@ -55,6 +55,16 @@ extern "C" int pt_device_count(void)
 
 struct TimedLaunch { int kind; hipEvent_t a, b; };
 
+// A lane = one HIP stream + one private set of wavefront streams.  Consecutive batches go to consecutive lanes, so
+// the low-occupancy late bounces of one batch overlap the wide early bounces of the next (the kernels of one batch
+// are a dependent chain; the chip is only full when several chains are in flight).
+#define PT_MAX_LANES 4
+struct Lane {
+    hipStream_t stream = nullptr;
+    DStreams st{};
+    hipEvent_t acc_done = nullptr;   // recorded after this lane's last k_accumulate (framebuffer order across lanes)
+};
+
 struct pt_ctx {
     int device = 0;
     pt_config cfg{};
@@ -64,11 +74,17 @@ struct pt_ctx {
     int seg_cap = 2048;
     int n_seg_max = 0;
     std::vector<void *> allocs;
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;   // lane 0's stream (stream may be caller-owned)
     hipEvent_t done_ev = nullptr;
+    Lane lanes[PT_MAX_LANES];
+    int n_lanes = 1;
+    int next_lane = 0;
+    int last_lane = -1;              // lane of the most recent batch (its acc_done orders the next accumulate)
+    int last_batch_lane = 0;
     bool fb_external = false;
     float4 *fb_own = nullptr;
-    DCounters *host_ctr = nullptr;   // pinned mirror, refreshed after every batch
+    DCounters *host_ctr = nullptr;   // pinned mirror of all banks, refreshed after every batch
+    DCounters host_sum{};            // banks summed (by sum_counters)
     DBatch last_batch{};
     bool have_last = false;
     // tile table of the current / last pt_render_tiles_async call (device copy + host mirror for reuse)
@@ -319,23 +335,36 @@ static int alloc_streams(pt_ctx *c)
     c->P = (int64_t)c->n_seg_max * c->seg_cap;
     const size_t P = (size_t)c->P;
     const size_t L = (size_t)std::max(c->cfg.light_samples, 1);
-    DStreams &st = c->st;
-    for (int i = 0; i < 2; i++) {
-        if (dev_alloc(c, &st.q[i].r0, P) || dev_alloc(c, &st.q[i].r1, P) || dev_alloc(c, &st.q[i].s0, P) ||
-            dev_alloc(c, &st.q[i].s1, P) || dev_alloc(c, &st.q[i].count, (size_t)c->n_seg_max))
-            return -1;
-    }
-    if (dev_alloc(c, &st.sq.p0, P) || dev_alloc(c, &st.sq.key, P) || dev_alloc(c, &st.sq.d, P * L) ||
-        dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
-        return -1;
-    if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
+    // framebuffer and counters are shared by the lanes
     if (dev_alloc(c, &c->fb_own, (size_t)c->cfg.width * c->cfg.height)) return -1;
-    st.fb = c->fb_own;
-    if (dev_alloc(c, &st.counters, 1)) return -1;
-    HIP_TRY(hipMemset(st.fb, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
-    HIP_TRY(hipMemset(st.counters, 0, sizeof(DCounters)));
-    HIP_TRY(hipHostMalloc((void **)&c->host_ctr, sizeof(DCounters)));
-    memset(c->host_ctr, 0, sizeof(DCounters));
+    DCounters *ctr = nullptr;
+    if (dev_alloc(c, &ctr, PT_COUNTER_BANKS)) return -1;
+    HIP_TRY(hipMemset(c->fb_own, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
+    HIP_TRY(hipMemset(ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS));
+    // small renders (a few batches at most) do not need the extra lanes' memory
+    const char *env = getenv("PATHTRACE_HIP_LANES");
+    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : PT_MAX_LANES;
+    for (int l = 0; l < c->n_lanes; l++) {
+        Lane &ln = c->lanes[l];
+        DStreams &st = ln.st;
+        for (int i = 0; i < 2; i++) {
+            if (dev_alloc(c, &st.q[i].r0, P) || dev_alloc(c, &st.q[i].r1, P) || dev_alloc(c, &st.q[i].s0, P) ||
+                dev_alloc(c, &st.q[i].s1, P) || dev_alloc(c, &st.q[i].count, (size_t)c->n_seg_max))
+                return -1;
+        }
+        if (dev_alloc(c, &st.sq.p0, P) || dev_alloc(c, &st.sq.key, P) || dev_alloc(c, &st.sq.d, P * L) ||
+            dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
+            return -1;
+        if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
+        st.fb = c->fb_own;
+        st.counters = ctr;
+        if (l == 0) ln.stream = c->own_stream;
+        else HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ln.acc_done, hipEventDisableTiming));
+    }
+    c->st = c->lanes[0].st;
+    HIP_TRY(hipHostMalloc((void **)&c->host_ctr, sizeof(DCounters) * PT_COUNTER_BANKS));
+    memset(c->host_ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS);
     return 0;
 }
 
@@ -371,13 +400,32 @@ extern "C" void pt_destroy(pt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int l = 0; l < c->n_lanes; l++)
+        if (c->lanes[l].stream) (void)hipStreamSynchronize(c->lanes[l].stream);
+    for (int l = 0; l < c->n_lanes; l++) {
+        if (c->lanes[l].acc_done) (void)hipEventDestroy(c->lanes[l].acc_done);
+        if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
+    }
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->host_ctr) (void)hipHostFree(c->host_ctr);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+// sum of the counter banks in the pinned mirror (monotone words written by the device; a poll may see a mix of two
+// consecutive copies, which is still a valid lower bound)
+static const DCounters &sum_counters(pt_ctx *c)
+{
+    DCounters s{};
+    unsigned long long *d = (unsigned long long *)&s;
+    for (int b = 0; b < PT_COUNTER_BANKS; b++) {
+        const unsigned long long *h = (const unsigned long long *)&c->host_ctr[b];
+        for (int k = 0; k < 10; k++) d[k] += h[k];
+    }
+    c->host_sum = s;
+    return c->host_sum;
 }
 
 static hipEvent_t get_event(pt_ctx *c, size_t i)
@@ -391,19 +439,19 @@ static hipEvent_t get_event(pt_ctx *c, size_t i)
 }
 
 struct Timer {
-    pt_ctx *c; int kind; bool on; hipEvent_t a = nullptr, b = nullptr;
-    Timer(pt_ctx *c_, int kind_) : c(c_), kind(kind_), on(c_->profiling)
+    pt_ctx *c; int kind; bool on; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr;
+    Timer(pt_ctx *c_, int kind_, hipStream_t s_) : c(c_), kind(kind_), on(c_->profiling), stream(s_)
     {
         if (!on) return;
         size_t i = c->timed.size() * 2;
         a = get_event(c, i); b = get_event(c, i + 1);
         if (!a || !b) { on = false; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, stream);
     }
     ~Timer()
     {
         if (!on) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, stream);
         c->timed.push_back({kind, a, b});
     }
 };
@@ -411,19 +459,30 @@ struct Timer {
 static int run_batch(pt_ctx *c, const DBatch &b)
 {
     const DScene &S = c->S;
-    const DStreams &st = c->st;
-    { Timer t(c, PT_K_GENERATE); launch_generate(S, st, b, c->stream); }
+    const int li = c->next_lane;
+    c->next_lane = (c->next_lane + 1) % c->n_lanes;
+    Lane &ln = c->lanes[li];
+    DStreams st = ln.st;
+    st.fb = c->st.fb;   // the (possibly caller-owned) framebuffer is shared
+    hipStream_t sm = ln.stream;
+    { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }
     int qi = 0;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
-        { Timer t(c, PT_K_EXTEND); launch_extend(S, st, b, qi, bounce, c->stream); }
-        { Timer t(c, PT_K_SHADE); launch_shade(S, st, b, qi, bounce, c->stream); }
-        if (S.light_samples > 0) { Timer t(c, PT_K_CONNECT); launch_connect(S, st, b, bounce, c->stream); }
+        { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, b, qi, bounce, sm); }
+        { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, b, qi, bounce, sm); }
+        { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, b, bounce, sm); }
         qi ^= 1;
     }
-    { Timer t(c, PT_K_ACCUMULATE); launch_accumulate(S, st, b, c->stream); }
+    // framebuffer[j][i] += col must happen in sample order per pixel (float addition is not associative): every
+    // accumulate waits for the previous batch's accumulate, whichever lane that ran on
+    if (c->last_lane >= 0 && c->last_lane != li) HIP_TRY(hipStreamWaitEvent(sm, c->lanes[c->last_lane].acc_done, 0));
+    { Timer t(c, PT_K_ACCUMULATE, sm); launch_accumulate(S, st, b, sm); }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->host_ctr, st.counters, sizeof(DCounters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->host_ctr, st.counters, sizeof(DCounters) * PT_COUNTER_BANKS, hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipEventRecord(ln.acc_done, sm));
+    c->last_lane = li;
     c->last_batch = b;
+    c->last_batch_lane = li;
     c->have_last = true;
     return 0;
 }
@@ -499,7 +558,7 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
     const bool same = table.size() == c->h_tiles.size() &&
                       (table.empty() || memcmp(table.data(), c->h_tiles.data(), table.size() * sizeof(DTile)) == 0);
     if (!same) {
-        HIP_TRY(hipStreamSynchronize(c->stream));   // earlier batches may still read the old table
+        for (int l = 0; l < c->n_lanes; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));   // old table may be in use
         if (table.size() > c->d_tiles_cap) {
             if (dev_alloc(c, &c->d_tiles, table.size() * 2)) return -1;
             c->d_tiles_cap = table.size() * 2;
@@ -509,7 +568,8 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
     }
     for (const Group &g : groups)
         if (render_group(c, bands, band_h, g.g0, g.g1, g.off, spp_begin, spp_end)) return -1;
-    HIP_TRY(hipEventRecord(c->done_ev, c->stream));
+    // the last accumulate transitively waited for every earlier accumulate, i.e. for every earlier batch
+    HIP_TRY(hipEventRecord(c->done_ev, c->lanes[c->last_lane].stream));
     return 0;
 }
 
@@ -524,8 +584,9 @@ extern "C" int pt_poll(pt_ctx *c, uint64_t *samples_done, uint64_t *rays_done)
 {
     if (!c) { set_err("pt_poll: null ctx"); return -1; }
     hipError_t e = hipEventQuery(c->done_ev);
-    if (samples_done) *samples_done = c->host_ctr->camera_samples;
-    if (rays_done) *rays_done = c->host_ctr->rays;
+    const DCounters &hs = sum_counters(c);
+    if (samples_done) *samples_done = hs.camera_samples;
+    if (rays_done) *rays_done = hs.rays;
     if (e == hipSuccess) return 1;
     if (e == hipErrorNotReady) return 0;
     set_err("pt_poll: %s", hipGetErrorString(e));
@@ -542,7 +603,7 @@ static int collect_times(pt_ctx *c)
         kt.launches[t.kind]++;
         kt.ms[t.kind] += ms;
     }
-    const DCounters &n = *c->host_ctr, &o = c->ctr_at_profile_start;
+    const DCounters n = sum_counters(c), &o = c->ctr_at_profile_start;
     kt.units[PT_K_GENERATE] = n.camera_samples - o.camera_samples;
     kt.units[PT_K_EXTEND] = n.ext_rays - o.ext_rays;
     kt.units[PT_K_SHADE] = n.ext_rays - o.ext_rays;
@@ -562,7 +623,7 @@ static int collect_times(pt_ctx *c)
 extern "C" int pt_wait(pt_ctx *c)
 {
     if (!c) { set_err("pt_wait: null ctx"); return -1; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int l = 0; l < c->n_lanes; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
     return collect_times(c);
 }
 
@@ -586,9 +647,10 @@ extern "C" int pt_clear_framebuffer(pt_ctx *c)
     if (!c) { set_err("pt_clear_framebuffer: null ctx"); return -1; }
     if (pt_wait(c)) return -1;
     HIP_TRY(hipMemsetAsync(c->st.fb, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height, c->stream));
-    HIP_TRY(hipMemsetAsync(c->st.counters, 0, sizeof(DCounters), c->stream));
+    HIP_TRY(hipMemsetAsync(c->st.counters, 0, sizeof(DCounters) * PT_COUNTER_BANKS, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    memset(c->host_ctr, 0, sizeof(DCounters));
+    c->last_lane = -1;
+    memset(c->host_ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS);
     c->ctr_at_profile_start = DCounters{};
     return 0;
 }
@@ -597,7 +659,7 @@ extern "C" int pt_get_counters(pt_ctx *c, pt_counters *out)
 {
     if (!c || !out) { set_err("pt_get_counters: null argument"); return -1; }
     if (pt_wait(c)) return -1;
-    const DCounters &d = *c->host_ctr;
+    const DCounters &d = sum_counters(c);
     out->camera_samples = d.camera_samples;
     out->rays = d.rays; out->extension_rays = d.ext_rays; out->extension_hits = d.ext_hits; out->shadow_rays = d.shadow_rays;
     out->term_miss = d.term_miss; out->term_rr = d.term_rr; out->term_emitter = d.term_emitter;
@@ -624,7 +686,10 @@ extern "C" int pt_set_stream(pt_ctx *c, void *s)
 {
     if (!c) { set_err("pt_set_stream: null ctx"); return -1; }
     if (pt_wait(c)) return -1;
+    // a caller-owned stream means the caller orders the work: run everything on it, one lane
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->lanes[0].stream = c->stream;
+    if (s) { c->n_lanes = 1; c->next_lane = 0; }
     return 0;
 }
 extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
@@ -634,7 +699,7 @@ extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
     c->profiling = enabled != 0;
     c->ktimes = pt_kernel_times{};
     c->timed.clear();
-    c->ctr_at_profile_start = *c->host_ctr;
+    c->ctr_at_profile_start = sum_counters(c);
     return 0;
 }
 extern "C" int pt_get_kernel_times(pt_ctx *c, pt_kernel_times *out)
@@ -650,7 +715,7 @@ extern "C" int pt_read_last_batch_radiance(pt_ctx *c, float *rgba, size_t max_re
     if (pt_wait(c)) return -1;
     if (!c->have_last) { *n_records = 0; return 0; }
     size_t n = std::min<size_t>((size_t)c->last_batch.n_paths, max_records);
-    HIP_TRY(hipMemcpy(rgba, c->st.radiance, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rgba, c->lanes[c->last_batch_lane].st.radiance, n * sizeof(float4), hipMemcpyDeviceToHost));
     *n_records = n;
     return 0;
 }

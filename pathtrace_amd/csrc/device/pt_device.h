@@ -109,11 +109,16 @@ struct DShadowQueue {    // per surviving hit: 16 B + light_samples * 24 B
     float2 *e;           // [k][P]: coef.y, coef.z
     int32_t *count;      // [n_seg]
 };
-struct DCounters {
+struct DCounters {       // one bank; padded to 128 B so that banks never share a cache line
     unsigned long long camera_samples;
     unsigned long long rays, ext_rays, ext_hits, shadow_rays;
     unsigned long long term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
+    unsigned long long pad[6];
 };
+// Every workgroup adds its counts with a handful of atomics; on ONE set of words the ~4000 workgroups of a launch
+// serialise at the memory-side atomic rate (about 90 adds per microsecond per word), which was a 50-100 us floor per
+// launch.  The counters are therefore banked by workgroup index and summed on the host.
+#define PT_COUNTER_BANKS 256
 struct DTile { int32_t x0, y0, w, pix0; };   // pix0 = first batch-local pixel index of this tile
 struct DBatch {
     // the batch covers n_tiles pixel rects (image tiles, reference queue.h:121-127); batch-local pixel pl lives
@@ -134,7 +139,7 @@ struct DStreams {
     float4 *radiance;            // [P]: per camera sample radiance sum (rgb, unused)
     float4 *pending;             // [P]: second emitter addition (integrator.h:319), applied by connect
     float4 *fb;                  // [height*width] rgba framebuffer SUM
-    DCounters *counters;
+    DCounters *counters;         // [PT_COUNTER_BANKS]
 };
 
 }  // namespace ptd

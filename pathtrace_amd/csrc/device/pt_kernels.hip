@@ -589,12 +589,13 @@ DEVI void batch_pixel(const DBatch &b, int pl, int &pi, int &pj)
     pj = y0 + py;
 }
 enum { C_SAMPLES = 0, C_RAYS, C_EXT, C_EXT_HITS, C_SHADOW, C_MISS, C_RR, C_EMIT, C_PDF, C_LIMIT, C_N };
+DEVI DCounters *counter_bank(DCounters *g) { return g + (blockIdx.x & (PT_COUNTER_BANKS - 1)); }
 DEVI void flush_counters(unsigned int *sh_ctr, DCounters *g)
 {
     __syncthreads();
     if (threadIdx.x < C_N) {
         unsigned long long v = sh_ctr[threadIdx.x];
-        if (v) atomicAdd(((unsigned long long *)g) + threadIdx.x, v);
+        if (v) atomicAdd(((unsigned long long *)counter_bank(g)) + threadIdx.x, v);
     }
 }
 
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
     }
     if (threadIdx.x == 0) {
         q.count[seg] = n;
-        if (n) atomicAdd(&st.counters->camera_samples, (unsigned long long)n);
+        if (n) atomicAdd(&counter_bank(st.counters)->camera_samples, (unsigned long long)n);
     }
 }
 
@@ -682,8 +683,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0) {
-        atomicAdd(&st.counters->rays, (unsigned long long)n);
-        atomicAdd(&st.counters->ext_rays, (unsigned long long)n);
+        atomicAdd(&counter_bank(st.counters)->rays, (unsigned long long)n);
+        atomicAdd(&counter_bank(st.counters)->ext_rays, (unsigned long long)n);
     }
 }
 
@@ -959,8 +960,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__res
     }
     if (threadIdx.x == 0) {
         const unsigned long long nr = (unsigned long long)n * L;
-        atomicAdd(&st.counters->rays, nr);
-        atomicAdd(&st.counters->shadow_rays, nr);
+        atomicAdd(&counter_bank(st.counters)->rays, nr);
+        atomicAdd(&counter_bank(st.counters)->shadow_rays, nr);
     }
 }
 
