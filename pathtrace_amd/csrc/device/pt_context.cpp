@@ -467,10 +467,16 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     hipStream_t sm = ln.stream;
     { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }
     int qi = 0;
+    DBatch bb = b;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
-        { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, b, qi, bounce, sm); }
-        { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, b, qi, bounce, sm); }
-        { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, b, bounce, sm); }
+        // segments merge pairwise from one bounce to the next (pt_device.h DBatch) until one is left
+        static const bool no_merge = getenv("PT_NO_MERGE") != nullptr;
+        if (bb.n_seg > 1 && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
+        else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
+        { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm); }
+        { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, bb, qi, bounce, sm); }
+        { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, bb, bounce, sm); }
+        bb.n_seg = bb.n_seg_out; bb.seg_cap = bb.seg_cap_out;
         qi ^= 1;
     }
     // framebuffer[j][i] += col must happen in sample order per pixel (float addition is not associative): every
@@ -505,6 +511,8 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         b.seg_cap = c->seg_cap;
         b.n_paths = npix * ns;
         b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
+        b.n_seg_out = b.n_seg; b.seg_cap_out = b.seg_cap;
+        b.P = c->P;
         if (run_batch(c, b)) return -1;
         s += ns;
     }

@@ -92,9 +92,9 @@ struct DScene {
 };
 
 // ---- wavefront streams in HBM -----------------------------------------------------------------------
-// A batch owns P = n_seg * seg_cap path slots.  Slot s of segment g lives at g*seg_cap + s.  Queues are
-// *segmented*: block g compacts the survivors of segment g to the front of the same segment of the
-// output queue, so compaction needs no global atomics and the layout is deterministic.
+// A batch owns P path slots cut into segments.  Slot s of segment g lives at g*seg_cap + s.  Queues are
+// *segmented*: a workgroup takes one 256-lane chunk of one segment and appends its survivors to the output
+// segment with ONE atomicAdd on that segment's counter (a few workgroups per counter: no hot word).
 struct DQueue {          // path queue: 64 B per path
     float4 *r0;          // origin.xyz, bits(slot)
     float4 *r1;          // direction.xyz, last_bsdf_pdf
@@ -129,7 +129,14 @@ struct DBatch {
     const DTile *tiles;          // device array [n_tiles + 1] (last entry: pix0 = npix), only read when n_tiles > 1
     int32_t npix;                // pixels in the batch
     int32_t s0, ns;              // first sample index, samples in the batch
-    int32_t n_seg, seg_cap;      // segmentation of the P = n_seg*seg_cap slots
+    // Segmentation of the P slots.  Bounce b reads queues cut into n_seg segments of seg_cap slots and writes its
+    // survivors into n_seg_out segments of seg_cap_out = 2*seg_cap slots (segment g -> g >> 1; the two source
+    // regions are adjacent, so the merged segment is exactly their union and can never overflow).  The number of
+    // live paths roughly halves per bounce, so segments -- and with them the 256-lane chunks the workgroups take --
+    // stay full instead of thinning out.
+    int32_t n_seg, seg_cap;
+    int32_t n_seg_out, seg_cap_out;
+    int64_t P;                   // allocated slots (plane stride of the shadow queue)
     int64_t n_paths;             // npix*ns  (<= P)
 };
 struct DStreams {

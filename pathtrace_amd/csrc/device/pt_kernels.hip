@@ -24,6 +24,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pt_device.h"
 
@@ -659,19 +660,38 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][1][PT_BLOCK]
-    const int seg = blockIdx.x;
+    // Persistent workgroups: a launch has at most a few thousand workgroups (dispatching a 256-thread workgroup costs
+    // 3-15 ns of serial dispatcher time on MI355X, which dominated the thin late bounces when every chunk was its own
+    // workgroup), and each strides over the 256-lane chunks of the segmented queue; empty chunks cost one scalar load.
+    const int cps = b.seg_cap / PT_BLOCK;
+    const int total_chunks = b.n_seg * cps;
     const DQueue q = st.q[qi];
-    const int n = q.count[seg];
-    if (n == 0) return;
-    const long long seg_base = (long long)seg * b.seg_cap;
     const uint32_t base_dim = DIM_BOUNCE0 + (uint32_t)bounce * dims_per_bounce(S);
     const bool has_vol = S.n_vol > 0;
-    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+    unsigned long long n_rays = 0;
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+        // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
+        // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
+        const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;
+        if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
+            // zero the counters this bounce's shade will append to (segment g -> g >> 1; every output segment has an
+            // even source).  The other path queue and the shadow queue are idle now: their last readers were the
+            // previous bounce's kernels on this stream.
+            const int so = b.n_seg_out == b.n_seg ? seg : (seg >> 1);
+            st.q[qi ^ 1].count[so] = 0;
+            st.sq.count[so] = 0;
+            if (b.n_seg_out == b.n_seg && seg + 1 < b.n_seg) { st.q[qi ^ 1].count[seg + 1] = 0; st.sq.count[seg + 1] = 0; }
+        }
+        const int n = q.count[seg];
+        const int i0 = chunk * PT_BLOCK;
+        if (i0 >= n) continue;
+        const long long seg_base = (long long)seg * b.seg_cap;
         const int i = i0 + threadIdx.x;
         const bool valid = i < n;
+        n_rays += (unsigned long long)((n - i0) < PT_BLOCK ? (n - i0) : PT_BLOCK);
         // whole wave beyond the end: nothing to do (wave-uniform exit keeps the sweep convergent)
-        if (((i0 + (int)(threadIdx.x & ~63u)) >= n)) continue;
-        const long long pos = seg_base + (valid ? i : 0);
+        if ((i0 + (int)(threadIdx.x & ~63u)) >= n) continue;
+        const long long pos = seg_base + (valid ? i : i0);
         float4 r0 = q.r0[pos], r1 = q.r1[pos];
         uint32_t k0 = 0, k1 = 0;
         if (has_vol) { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
@@ -682,9 +702,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         world_hit_n<1>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
-    if (threadIdx.x == 0) {
-        atomicAdd(&counter_bank(st.counters)->rays, (unsigned long long)n);
-        atomicAdd(&counter_bank(st.counters)->ext_rays, (unsigned long long)n);
+    if (threadIdx.x == 0 && n_rays) {
+        atomicAdd(&counter_bank(st.counters)->rays, n_rays);
+        atomicAdd(&counter_bank(st.counters)->ext_rays, n_rays);
     }
 }
 
@@ -700,16 +720,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     __shared__ int sh4[PT_BLOCK / 64];
+    __shared__ int sh_base[2];
     __shared__ unsigned int sh_ctr[C_N];
-    const int seg = blockIdx.x;
+    const int cps = b.seg_cap / PT_BLOCK;
+    const int total_chunks = b.n_seg * cps;
     const DQueue q = st.q[qi];
     const DQueue qo = st.q[qi ^ 1];
     const DShadowQueue sq = st.sq;
-    const int n = q.count[seg];
     if (threadIdx.x < C_N) sh_ctr[threadIdx.x] = 0;
     __syncthreads();
-    const long long seg_base = (long long)seg * b.seg_cap;
-    const long long P = (long long)b.n_seg * b.seg_cap;
+    const long long P = b.P;
     const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
     const uint32_t D = NV + L * (3u + NV) + 4u;
     const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
@@ -717,8 +737,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
     const bool last_bounce = (bounce + 1 >= S.max_bounces);
     const float pick_pdf = (float)S.n_lights;   // integrator.h:224
     (void)pick_pdf;
-    int out_n = 0, sh_n = 0;
-    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
+        const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;   // chunk-major, see k_extend
+        const int n = q.count[seg];
+        const int i0 = chunk * PT_BLOCK;
+        if (i0 >= n) continue;
+        const long long seg_base = (long long)seg * b.seg_cap;
+        const int seg_o = b.n_seg_out == b.n_seg ? seg : (seg >> 1);
+        const long long seg_base_o = (long long)seg_o * b.seg_cap_out;
         const int i = i0 + threadIdx.x;
         const bool valid = i < n;
         bool cont = false, shadow = false, pending = false;
@@ -814,8 +840,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
         int tot_c, tot_s;
         const int off_c = block_compact(cont, tot_c, sh4);
         const int off_s = block_compact(shadow, tot_s, sh4);
+        // one atomicAdd per workgroup and queue reserves this chunk's range in the output segment
+        if (threadIdx.x == 0) {
+            sh_base[0] = tot_c ? atomicAdd(&qo.count[seg_o], tot_c) : 0;
+            sh_base[1] = tot_s ? atomicAdd(&sq.count[seg_o], tot_s) : 0;
+        }
+        __syncthreads();
         if (cont) {
-            const long long o = seg_base + out_n + off_c;
+            const long long o = seg_base_o + sh_base[0] + off_c;
             qo.r0[o] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
             qo.r1[o] = make_float4(nB.x, nB.y, nB.z, new_pdf);
             qo.s0[o] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
@@ -823,7 +855,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
         }
         if (shadow) {
             // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
-            const long long o = seg_base + sh_n + off_s;
+            const long long o = seg_base_o + sh_base[1] + off_s;
             sq.p0[o] = make_float4(hp.x, hp.y, hp.z, __int_as_float(slot | (pending ? (int)0x80000000 : 0)));
             if (NV) sq.key[o] = make_uint2(k0, k1);
             const bool att_ok = (double)vlen(att) > 0.0001;   // integrator.h:248
@@ -856,12 +888,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
                 }
             }
         }
-        out_n += tot_c;
-        sh_n += tot_s;
-    }
-    if (threadIdx.x == 0) {
-        qo.count[seg] = out_n;
-        sq.count[seg] = sh_n;
     }
     flush_counters(sh_ctr, st.counters);
 }
@@ -898,21 +924,27 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__res
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][max(NR,1)][PT_BLOCK]
-    const int seg = blockIdx.x;
+    // the shadow queue was written by this bounce's shade in the OUTPUT segmentation
+    const int cps = b.seg_cap_out / PT_BLOCK;
+    const int total_chunks = b.n_seg_out * cps;
     const DShadowQueue sq = st.sq;
-    const int n = sq.count[seg];
-    if (n == 0) return;
-    const long long seg_base = (long long)seg * b.seg_cap;
-    const long long P = (long long)b.n_seg * b.seg_cap;
+    const long long P = b.P;
     const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
     const uint32_t D = NV + L * (3u + NV) + 4u;
     const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
     const float pick_pdf = (float)S.n_lights;   // integrator.h:224
-    for (int i0 = 0; i0 < n; i0 += PT_BLOCK) {
+    unsigned long long n_rays = 0;
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
+        const int chunk = c / b.n_seg_out, seg = c - chunk * b.n_seg_out;   // chunk-major, see k_extend
+        const int n = sq.count[seg];
+        const int i0 = chunk * PT_BLOCK;
+        if (i0 >= n) continue;
+        const long long seg_base = (long long)seg * b.seg_cap_out;
         const int i = i0 + threadIdx.x;
         const bool valid = i < n;
-        if (((i0 + (int)(threadIdx.x & ~63u)) >= n)) continue;
-        const long long pos = seg_base + (valid ? i : 0);
+        n_rays += (unsigned long long)((n - i0) < PT_BLOCK ? (n - i0) : PT_BLOCK) * L;
+        if ((i0 + (int)(threadIdx.x & ~63u)) >= n) continue;
+        const long long pos = seg_base + (valid ? i : i0);
         const float4 p0 = sq.p0[pos];
         const v3 hp = V(p0.x, p0.y, p0.z);
         const int slotw = __float_as_int(p0.w);
@@ -958,10 +990,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__res
             st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
         }
     }
-    if (threadIdx.x == 0) {
-        const unsigned long long nr = (unsigned long long)n * L;
-        atomicAdd(&counter_bank(st.counters)->rays, nr);
-        atomicAdd(&counter_bank(st.counters)->shadow_rays, nr);
+    if (threadIdx.x == 0 && n_rays) {
+        atomicAdd(&counter_bank(st.counters)->rays, n_rays);
+        atomicAdd(&counter_bank(st.counters)->shadow_rays, n_rays);
     }
 }
 
@@ -989,6 +1020,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
+// at most PT_GRID_MAX workgroups per launch (256 CUs x 8): enough to fill the chip, few enough to dispatch quickly
+static int g_grid_max = 0;
+static int persistent_grid(long long chunks)
+{
+    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 2048; if (g_grid_max < 1) g_grid_max = 2048; }
+    return (int)(chunks < g_grid_max ? chunks : g_grid_max);
+}
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
     hipLaunchKernelGGL(k_generate, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b);
@@ -996,21 +1034,21 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const size_t lds = (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    hipLaunchKernelGGL(k_extend, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    hipLaunchKernelGGL(k_extend, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shade, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    hipLaunchKernelGGL(k_shade, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
     const int L = S.light_samples;
     const int nr = (L == 1 || L == 2 || L == 4) ? L : 0;
     const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
-    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else hipLaunchKernelGGL(k_connect<0>, dim3(b.n_seg), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    else hipLaunchKernelGGL(k_connect<0>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
