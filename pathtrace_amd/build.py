@@ -24,8 +24,10 @@ HEADERS = [
     os.path.join(HERE, "..", "include", "pathtrace_hip.h"),
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-function"]
+# -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 mul/add into v_pk_*_f32, whose SGPR operands must be
+# aligned pairs -- every packed op then costs two s_mov on the (single per CU) scalar unit and extra VGPRs.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
 
 
 def needs_build() -> bool:

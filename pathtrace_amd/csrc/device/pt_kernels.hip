@@ -197,6 +197,15 @@ DEVI bool sphere_hit_t(const DPrim &s, v3 A, v3 B, float t_min, float t_max, flo
 // ---- leaf tests on NR rays that share one origin (NR = 1: extension ray; NR = light_samples: the shadow rays of
 // one hit).  The local origin (ray::apply ray.h:20-24) and every numerator that depends only on it are computed
 // once; each ray's own arithmetic is exactly the single-ray sequence.
+//
+// All per-lane decisions are kept in the VECTOR unit: a CU has one scalar ALU for its four SIMDs, and the first
+// version of this sweep spent 0.83 scalar instructions per vector instruction on exec-mask branches and on and/or of
+// compare results -- the scalar unit, not the VALU, set the pace.  The reference's chains of comparisons are
+// therefore restated as one "excess" value e whose sign decides, with identical NaN behaviour:
+//     (a < lo || a > hi)   <=>   fmaxf(lo - a, a - hi) > 0
+// for every float a: a - b > 0 <=> a > b exactly (subnormals are kept, so a != b never subtracts to 0), infinities give
+// +-inf with the right sign, and a NaN a makes both differences NaN, which fmaxf ignores -- exactly like the
+// reference's comparisons, which are all false for NaN so that a NaN t or hit coordinate is NOT rejected.
 template <int PLANE>   // 0 XY, 1 XZ, 2 YZ: which local component is the plane axis / x / z (primitive.h:104-121)
 DEVI void rect_axes(v3 v, float &x, float &pl, float &z)
 {
@@ -204,38 +213,48 @@ DEVI void rect_axes(v3 v, float &x, float &pl, float &z)
     else if (PLANE == 2) { x = v.y; pl = v.x; z = v.z; }
     else { x = v.x; pl = v.y; z = v.z; }
 }
+// rect::hit primitive.h:186-206 with the shuffle resolved at compile time; num = y - o.y.
+// Returns the excess: the reference rejects the hit iff excess > 0.  t_out is always the quotient.
 template <int PLANE>
-DEVI bool rect_hit_axes(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float t0, float t1, float &t_out)
-{   // primitive.h:186-206 with the shuffle resolved at compile time; num = y - o.y
+DEVI float rect_excess(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float t0, float t1, float &t_out)
+{
     float dx, dpl, dz;
     rect_axes<PLANE>(Bl, dx, dpl, dz);
     const float t = num / dpl;
-    if (t < t0 || t > t1) return false;
     const float xh = ox + t * dx;
     const float zh = oz + t * dz;
-    if (xh < x0 || xh > x1 || zh < z0 || zh > z1) return false;
     t_out = t;
-    return true;
+    const float et = fmaxf(t0 - t, t - t1);                                   // t < t0 || t > t1
+    const float ex = fmaxf(x0 - xh, xh - x1), ez = fmaxf(z0 - zh, zh - z1);   // xh < x0 || xh > x1 || zh < z0 || zh > z1
+    return fmaxf(et, fmaxf(ex, ez));
 }
-DEVI bool box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t0, float t1, float &t_out, int &face)
-{   // box::hit -> hittable_list::hit over the six sides in primitive.h:232-240 order; closest_so_far shrinks and a
-    // later side with an equal t replaces (hittable_list.h:27-35)
-    bool any = false;
+// box::hit -> hittable_list::hit over the six sides in primitive.h:232-240 order; closest_so_far shrinks and a later
+// side with an equal t replaces (hittable_list.h:27-35).  face = -1: no side hit.
+DEVI void box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t0, float t1, float &t_out, int &face)
+{
     float closest = t1, t;
-    if (rect_hit_axes<0>(p0[0], p0[1], p1[0], p1[1], p0[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t)) { any = true; closest = t; face = 0; }
-    if (rect_hit_axes<0>(p0[0], p0[1], p1[0], p1[1], p1[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t)) { any = true; closest = t; face = 1; }
-    if (rect_hit_axes<2>(p0[1], p0[2], p1[1], p1[2], p0[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 2; }
-    if (rect_hit_axes<2>(p0[1], p0[2], p1[1], p1[2], p1[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 3; }
-    if (rect_hit_axes<1>(p0[0], p0[2], p1[0], p1[2], p0[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 4; }
-    if (rect_hit_axes<1>(p0[0], p0[2], p1[0], p1[2], p1[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t)) { any = true; closest = t; face = 5; }
+    int f = -1;
+    bool h;
+    h = !(rect_excess<0>(p0[0], p0[1], p1[0], p1[1], p0[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 0 : f;
+    h = !(rect_excess<0>(p0[0], p0[1], p1[0], p1[1], p1[2] - Al.z, Al.x, Al.y, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 1 : f;
+    h = !(rect_excess<2>(p0[1], p0[2], p1[1], p1[2], p0[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 2 : f;
+    h = !(rect_excess<2>(p0[1], p0[2], p1[1], p1[2], p1[0] - Al.x, Al.y, Al.z, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 3 : f;
+    h = !(rect_excess<1>(p0[0], p0[2], p1[0], p1[2], p0[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 4 : f;
+    h = !(rect_excess<1>(p0[0], p0[2], p1[0], p1[2], p1[1] - Al.y, Al.x, Al.z, Bl, t0, closest, t) > 0.0f); closest = h ? t : closest; f = h ? 5 : f;
     t_out = closest;
-    return any;
+    face = f;
 }
 
 // ------------------------------------------------------------------------------------------------
 // World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep over NR rays per lane
 // that share the origin A.  Returns per ray id = -1 (miss) or instance*8 + face, and t.  `stk` points at this
 // lane's column of the LDS short stack, laid out [slot][ray][PT_BLOCK] float2.
+//
+// Lane masking without branches.  skip[r] is the pc at which ray r becomes active again after missing a box
+// (0 = active).  Invariants used below: (i) a masked ray has cur_id = -1 (set when it missed the box) and keeps it;
+// (ii) its skip is the end of an ENCLOSING subtree, hence >= the end op_a of any node met while masked, so
+// skip = max(skip, miss ? op_a : 0) leaves masked rays alone; (iii) stack slots written inside a skipped subtree are
+// dead for that ray, so pushes need no mask.
 // ------------------------------------------------------------------------------------------------
 template <int NR>
 DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
@@ -261,52 +280,52 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
 #define OPF(i) __int_as_float((i) < 8 ? w0[8 + (i)] : w1[(i) - 8])
         if (op_push >= 0) {
 #pragma unroll
-            for (int r = 0; r < NR; r++)
-                if (pc >= skip[r]) stk[(op_push * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
+            for (int r = 0; r < NR; r++) stk[(op_push * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
         }
         if (kind == OP_ENTER) {
-            // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays
+            // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays.
+            // "t0 > tmin ? t0 : tmin" keeps tmin when t0 is NaN = fmaxf(tmin, t0); likewise fminf for tmax; they are never
+            // NaN themselves, and tmin >= 0.001, tmax <= FLT_MAX rule out inf - inf, so "tmax <= tmin" <=> tmin - tmax >= 0.
             const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
             const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
-                float tmin = T_MIN, tmax = T_MAX;
-                bool ok = true;
-                {
-                    float t0 = dx0 * inv[r].x, t1 = dx1 * inv[r].x;
-                    if (inv[r].x < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-                    if (tmax <= tmin) ok = false;
-                }
-                {
-                    float t0 = dy0 * inv[r].y, t1 = dy1 * inv[r].y;
-                    if (inv[r].y < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-                    if (tmax <= tmin) ok = false;
-                }
-                {
-                    float t0 = dz0 * inv[r].z, t1 = dz1 * inv[r].z;
-                    if (inv[r].z < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
-                    tmin = t0 > tmin ? t0 : tmin; tmax = t1 < tmax ? t1 : tmax;
-                    if (tmax <= tmin) ok = false;
-                }
-                if (pc >= skip[r] && !ok) { cur_id[r] = -1; skip[r] = op_a; }
-            }
-            // no lane of the wave is inside this subtree any more (lanes masked by an enclosing miss resume at or
-            // after op_a as well): jump to the end of the subtree -- wave-uniform, costs one ballot
             bool any_in = false;
 #pragma unroll
-            for (int r = 0; r < NR; r++) any_in |= (pc >= skip[r]);
+            for (int r = 0; r < NR; r++) {
+                float tmin = T_MIN, tmax = T_MAX, e;
+                {
+                    const float a = dx0 * inv[r].x, c = dx1 * inv[r].x;
+                    const bool neg = inv[r].x < 0.0f;
+                    tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
+                    e = tmin - tmax;
+                }
+                {
+                    const float a = dy0 * inv[r].y, c = dy1 * inv[r].y;
+                    const bool neg = inv[r].y < 0.0f;
+                    tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
+                    e = fmaxf(e, tmin - tmax);
+                }
+                {
+                    const float a = dz0 * inv[r].z, c = dz1 * inv[r].z;
+                    const bool neg = inv[r].z < 0.0f;
+                    tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
+                    e = fmaxf(e, tmin - tmax);
+                }
+                const bool miss = e >= 0.0f;
+                cur_id[r] = miss ? -1 : cur_id[r];            // masked rays already hold -1
+                skip[r] = max(skip[r], miss ? op_a : 0);      // masked rays: skip >= op_a already
+                any_in |= (pc >= skip[r]);
+            }
+            // no ray of the wave is inside this subtree any more: jump to its end -- wave-uniform, one ballot
             if (!__any(any_in)) pc = op_a - 1;
-        } else if (kind == OP_COMBINE) {   // bvh.h:36-66
+        } else if (kind == OP_COMBINE) {   // bvh.h:36-66: left iff left.hit && (!right.hit || left.t < right.t)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                if (pc >= skip[r]) {
-                    const float2 l = stk[(op_slot * NR + r) * PT_BLOCK];
-                    const int lid = __float_as_int(l.y);
-                    const bool take_left = (lid >= 0) && ((cur_id[r] < 0) || (l.x < cur_t[r]));
-                    if (take_left) { cur_t[r] = l.x; cur_id[r] = lid; }
-                }
+                const float2 l = stk[(op_slot * NR + r) * PT_BLOCK];
+                const int lid = (pc >= skip[r]) ? __float_as_int(l.y) : -1;   // a masked ray keeps its -1
+                const int lt = (l.x < cur_t[r]) ? -1 : 0;
+                const int take = (~(lid >> 31)) & ((cur_id[r] >> 31) | lt);    // all-ones iff take left
+                cur_t[r] = take ? l.x : cur_t[r];
+                cur_id[r] = take ? lid : cur_id[r];
             }
         } else {
             // instance::hit primitive.h:298-312: local origin once, local direction per ray
@@ -318,32 +337,32 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 for (int r = 0; r < NR; r++) {
                     const v3 Bl = xf_linear(m, B[r]);
                     float t;
-                    int face = 0;
-                    const bool hit = box_hit_shared(q0, q1, Al, Bl, T_MIN, T_MAX, t, face);
-                    if (pc >= skip[r]) { cur_id[r] = hit ? (op_id_base + face) : -1; cur_t[r] = hit ? t : 0.0f; }
+                    int face;
+                    box_hit_shared(q0, q1, Al, Bl, T_MIN, T_MAX, t, face);
+                    const bool hit = (face >= 0) && (pc >= skip[r]);
+                    cur_id[r] = hit ? (op_id_base + face) : -1;
+                    cur_t[r] = hit ? t : cur_t[r];
                 }
             } else if (kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const v3 Bl = xf_linear(m, B[r]);
-                    bool hit = false;
-                    float t = 0.0f, t1v, t2v;
-                    int f;
-                    if (box_hit_shared(q0, q1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f)) {
-                        if (box_hit_shared(q0, q1, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f)) {
-                            if (t1v < T_MIN) t1v = T_MIN;
-                            if (t2v > T_MAX) t2v = T_MAX;
-                            if (!(t1v >= t2v)) {
-                                if (t1v < 0) t1v = 0;
-                                const float dlen = vlen(Bl);
-                                const float distance_inside = (t2v - t1v) * dlen;
-                                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
-                                const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
-                                if (hit_distance < distance_inside) { t = t1v + hit_distance / dlen; hit = true; }
-                            }
-                        }
-                    }
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    float t1v, t2v;
+                    int f1, f2;
+                    box_hit_shared(q0, q1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_shared(q0, q1, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                    bool hit = (f1 >= 0) && (f2 >= 0);
+                    t1v = (t1v < T_MIN) ? T_MIN : t1v;
+                    t2v = (t2v > T_MAX) ? T_MAX : t2v;
+                    hit = hit && !(t1v >= t2v);
+                    t1v = (t1v < 0) ? 0.0f : t1v;
+                    const float dlen = vlen(Bl);
+                    const float distance_inside = (t2v - t1v) * dlen;
+                    const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
+                    const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
+                    hit = hit && (hit_distance < distance_inside) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? (t1v + hit_distance / dlen) : cur_t[r];
                 }
             } else if (kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95
                 const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
@@ -354,17 +373,11 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     const float a = vdot(Bl, Bl);
                     const float b = vdot(oc, Bl);
                     const float disc = b * b - a * c;
-                    bool hit = false;
-                    float t = 0.0f;
-                    if (disc > 0) {
-                        float temp = (-b - sqrtf(disc)) / a;
-                        if (temp < T_MAX && temp > T_MIN) { t = temp; hit = true; }
-                        else {
-                            temp = (-b + sqrtf(disc)) / a;
-                            if (temp < T_MAX && temp > T_MIN) { t = temp; hit = true; }
-                        }
-                    }
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    const float ta = (-b - sqrtf(disc)) / a, tb = (-b + sqrtf(disc)) / a;
+                    const bool ha = (ta < T_MAX) && (ta > T_MIN), hb = (tb < T_MAX) && (tb > T_MIN);
+                    const bool hit = (disc > 0) && (ha || hb) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? (ha ? ta : tb) : cur_t[r];
                 }
             } else {   // the three rect alignments (rect::hit primitive.h:186-225)
                 float ox, opl, oz;
@@ -375,17 +388,18 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const v3 Bl = xf_linear(m, B[r]);
-                    float t = 0.0f;
-                    bool hit;
-                    if (kind == OP_LEAF_RECT_XY) hit = rect_hit_axes<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else if (kind == OP_LEAF_RECT_YZ) hit = rect_hit_axes<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else hit = rect_hit_axes<1>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    if (pc >= skip[r]) { cur_id[r] = hit ? op_id_base : -1; cur_t[r] = hit ? t : 0.0f; }
+                    float t, e;
+                    if (kind == OP_LEAF_RECT_XY) e = rect_excess<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else if (kind == OP_LEAF_RECT_YZ) e = rect_excess<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else e = rect_excess<1>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    const bool hit = !(e > 0.0f) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? t : cur_t[r];
                 }
             }
         }
-    }
 #undef OPF
+    }
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
 }
@@ -1020,11 +1034,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
-// at most PT_GRID_MAX workgroups per launch (256 CUs x 8): enough to fill the chip, few enough to dispatch quickly
+// at most 4096 workgroups per launch (256 CUs x 8 resident x 2: measured better balanced than 2048), few enough to dispatch quickly
 static int g_grid_max = 0;
 static int persistent_grid(long long chunks)
 {
-    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 2048; if (g_grid_max < 1) g_grid_max = 2048; }
+    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096; }
     return (int)(chunks < g_grid_max ? chunks : g_grid_max);
 }
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
