@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): scenes/cornell_box.json, 1920x1080, max_bounces 10, light_samples 4, russian
-roulette on, normal_offset 1e-4.  One *step* = one wavefront pass over the whole frame at SPP_PER_STEP*N samples per
-pixel (one batch of ~8.3 M camera samples per GPU); the default K = 256 steps at N = 1 is exactly the 1024 spp of
+roulette on, normal_offset 1e-4.  One *step* = one wavefront pass over the whole frame at SPP_PER_STEP*N = 16 N samples
+per pixel (one batch of ~33 M camera samples per GPU); the default K = 64 steps at N = 1 is exactly the 1024 spp of
 configs[1].  "ray" = one World::hit query, extension + shadow, the reference's own unit (integrator.h:192,247).
 
 N > 1: one process per GPU; the image is partitioned by 128x128 tile in NaiveSpiral order, tile k -> rank k mod N
@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 1920, 1080
 SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
-SPP_PER_STEP = 4
+SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # SURVEY.md 8(d) byte model, per unit of each kernel
@@ -46,8 +46,8 @@ def shade_bytes(E, H, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scene", default=SCENE)
     args = ap.parse_args()
@@ -74,7 +74,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
 
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
-    r = pt.Renderer(scene, device=local_rank, seed=0)
+    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * SPP_PER_STEP)
     # render straight into a torch tensor so that the final reduce needs no copy
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
@@ -172,7 +172,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "scenes/cornell_box.json 1920x1080, iterative NEE path tracing, max_bounces 10, "
-                                   "light_samples 4, russian roulette, %d spp per step per frame (K=256 at N=1 is 1024 spp)" % spp_step,
+                                   "light_samples 4, russian roulette, %d spp per step per frame (K=64 at N=1 is 1024 spp)" % spp_step,
                        "spp_total": spp_step * args.steps, "camera_samples": int(total_samples), "rays": int(total_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],

@@ -143,29 +143,28 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
         const pt_primitive &p = sc->primitives[in.primitive];
         DOp op{};
         op.a = ii;
-        op.id_base = ii * 8;
         op.push_slot = pending_push;
         pending_push = -1;
         memcpy(op.f, in.inv, 12 * sizeof(float));
         switch (p.type) {
         case PT_PRIM_RECT:
             op.kind = p.plane == PT_PLANE_XY ? OP_LEAF_RECT_XY : (p.plane == PT_PLANE_YZ ? OP_LEAF_RECT_YZ : OP_LEAF_RECT_XZ);
-            memcpy(op.f + 12, p.rect, 5 * sizeof(float));
+            memcpy(op.g, p.rect, 5 * sizeof(float));
             break;
         case PT_PRIM_BOX:
             op.kind = OP_LEAF_BOX;
-            memcpy(op.f + 12, p.p0, 12); memcpy(op.f + 15, p.p1, 12);
+            memcpy(op.g, p.p0, 12); memcpy(op.g + 3, p.p1, 12);
             break;
         case PT_PRIM_SPHERE:
             op.kind = OP_LEAF_SPHERE;
-            memcpy(op.f + 12, p.center, 12); op.f[15] = p.radius;
+            memcpy(op.g, p.center, 12); op.g[3] = p.radius;
             break;
         case PT_PRIM_VOLUME: {
             const pt_primitive &bd = sc->primitives[p.boundary];
             if (bd.type == PT_PRIM_BOX) {
                 op.kind = OP_LEAF_VOLBOX;
-                memcpy(op.f + 12, bd.p0, 12); memcpy(op.f + 15, bd.p1, 12);
-                op.f[18] = p.density;
+                memcpy(op.g, bd.p0, 12); memcpy(op.g + 3, bd.p1, 12);
+                op.g[6] = p.density;
             } else return -2;   // only box boundaries (the reference's volume scenes); refused loudly by the caller
             break;
         }
@@ -292,7 +291,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         return -1;
     }
     for (DOp &op : ops)
-        if (op.kind == OP_LEAF_VOLBOX) op.vol_ord = insts[op.a].vol_ordinal;
+        if (op.kind == OP_LEAF_VOLBOX) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
+    ops.push_back(DOp{});   // padding: the sweep prefetches the first half of op[pc + 1]
     // emitted radiance by hit id (instance*8 + face): power * emit->value * emit->alpha (material.h:219), the same two
     // float multiplications the kernels would do (this file is compiled with -ffp-contract=off)
     std::vector<float4> emit((size_t)sc->n_instances * 8, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -309,7 +309,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
         return -1;
     S.n_insts = (int)insts.size(); S.n_prims = (int)prims.size(); S.n_mats = (int)mats.size();
-    S.n_ops = (int)ops.size(); S.n_lights = (int)lights.size(); S.n_vol = nvol;
+    S.n_ops = (int)ops.size() - 1; S.n_lights = (int)lights.size(); S.n_vol = nvol;
     S.stack_depth = std::max(max_depth, 1);
     const pt_camera &cm = sc->camera;
     memcpy(S.cam.origin, cm.origin, 12); memcpy(S.cam.llc, cm.lower_left_corner, 12);
@@ -343,7 +343,7 @@ static int alloc_streams(pt_ctx *c)
     HIP_TRY(hipMemset(ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS));
     // small renders (a few batches at most) do not need the extra lanes' memory
     const char *env = getenv("PATHTRACE_HIP_LANES");
-    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : PT_MAX_LANES;
+    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 2;   // 2 measured best (1: tails exposed, 4: no gain)
     for (int l = 0; l < c->n_lanes; l++) {
         Lane &ln = c->lanes[l];
         DStreams &st = ln.st;

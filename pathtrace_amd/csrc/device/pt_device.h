@@ -53,17 +53,17 @@ enum {
     OP_LEAF_RECT_YZ = 4,
     OP_LEAF_BOX = 5,     // f[0..11] inverse, f[12..14] = p0, f[15..17] = p1              (primitive.h:229-242)
     OP_LEAF_SPHERE = 6,  // f[0..11] inverse, f[12..14] = center, f[15] = radius
-    OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, vol_ord
+    OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, f[19] = bits(vol_ord)
 };
-struct DOp {             // 128 bytes, 128-byte aligned in the device array
+struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in the device array
+    // first half: everything an op needs FIRST (header + node box or instance matrix); it is prefetched one op ahead
     int32_t kind;
-    int32_t a;
+    int32_t a;           // ENTER: skip target;  LEAF: instance index (hit id = a*8 + face)
     int32_t slot;        // COMBINE: short-stack slot
     int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
-    int32_t id_base;     // LEAF: instance_index * 8
-    int32_t vol_ord;     // LEAF_VOLBOX: ordinal among volume instances (stream RNG dimension slot)
-    int32_t pad[2];
-    float f[24];
+    float f[12];
+    // second half: primitive parameters, needed only after the ray has been transformed
+    float g[16];         // g[i] = "f[12 + i]" of the table above
 };
 #define PT_MAX_STACK 8   // short-stack slots per lane and ray held in LDS (tree height <= 8)
 

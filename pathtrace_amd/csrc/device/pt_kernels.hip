@@ -272,12 +272,17 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         skip[r] = lane_valid ? 0 : 0x7fffffff;
     }
     const int n_ops = S.n_ops;
+    // Scalar-load pipeline: an op is two 64-byte halves.  The first half (header + box / matrix) of op pc+1 is
+    // requested while op pc executes; the second half (primitive parameters) of op pc is requested at the top of
+    // its iteration and is only waited for after the ray has been transformed.  Addresses depend on pc alone.
+    i32x16 w0 = *reinterpret_cast<const i32x16 *>(&S.ops[0]);
     for (int pc = 0; pc < n_ops; ++pc) {
-        // one op = two 64-byte scalar loads (s_load_dwordx16) whose address depends only on pc
-        const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc]);
         const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&S.ops[pc]) + 1);
-        const int kind = w0[0], op_a = w0[1], op_slot = w0[2], op_push = w0[3], op_id_base = w0[4], op_vol_ord = w0[5];
-#define OPF(i) __int_as_float((i) < 8 ? w0[8 + (i)] : w1[(i) - 8])
+        const i32x16 nxt = *reinterpret_cast<const i32x16 *>(&S.ops[pc + 1]);   // the array ends with a padding op
+        const int kind = w0[0], op_a = w0[1], op_slot = w0[2], op_push = w0[3];
+        const int op_id_base = op_a * 8;
+        bool jumped = false;
+#define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
         if (op_push >= 0) {
 #pragma unroll
             for (int r = 0; r < NR; r++) stk[(op_push * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
@@ -316,7 +321,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 any_in |= (pc >= skip[r]);
             }
             // no ray of the wave is inside this subtree any more: jump to its end -- wave-uniform, one ballot
-            if (!__any(any_in)) pc = op_a - 1;
+            if (!__any(any_in)) { pc = op_a - 1; jumped = true; }
         } else if (kind == OP_COMBINE) {   // bvh.h:36-66: left iff left.hit && (!right.hit || left.t < right.t)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -358,7 +363,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     t1v = (t1v < 0) ? 0.0f : t1v;
                     const float dlen = vlen(Bl);
                     const float distance_inside = (t2v - t1v) * dlen;
-                    const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)op_vol_ord);
+                    const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
                     const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
                     hit = hit && (hit_distance < distance_inside) && (pc >= skip[r]);
                     cur_id[r] = hit ? op_id_base : -1;
@@ -399,6 +404,8 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             }
         }
 #undef OPF
+        if (jumped) w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc + 1]);   // rare: the prefetched op is not the next one
+        else w0 = nxt;
     }
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
