@@ -80,11 +80,8 @@ def main():
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
     spp_step = SPP_PER_STEP * n
-    if n == 1:
-        my_tiles = [(0, 0, WIDTH, HEIGHT)]
-    else:
-        tiles = pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE)
-        my_tiles = tiles[rank::n]
+    from pathtrace_amd.distributed import reduce_framebuffer, tiles_for_rank
+    my_tiles = [(0, 0, WIDTH, HEIGHT)] if n == 1 else tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n)
 
     def step(i):
         r.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
@@ -106,8 +103,7 @@ def main():
     for i in range(args.steps):
         step(i)
     r.wait()
-    if dist is not None:
-        dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)   # the one exchange of the path
+    reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
     sync()
     dt = time.perf_counter() - t0
 

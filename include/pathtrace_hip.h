@@ -154,6 +154,14 @@ int pt_get_kernel_times(pt_ctx *ctx, pt_kernel_times *out);
  * n = (x1-x0)*(y1-y0)*(spp_end-spp_begin) records of 4 floats, sample-major then row-major pixels. */
 int pt_read_last_batch_radiance(pt_ctx *ctx, float *rgba, size_t max_records, size_t *n_records);
 
+/* Validation hook: World::hit (world.h:17-20, with the integrator's t range (0.001, FLT_MAX)) for caller-supplied
+ * rays, through the very traversal code the render kernels use.  n origins (float[3n]); rays_per_origin = 1 uses the
+ * extension-ray instantiation, 4 the shared-origin shadow-ray instantiation (dirs = float[3 * n * rays_per_origin]).
+ * k0, k1, vol_dim = stream RNG key and dimension base for constant_medium free-flight draws.  Outputs per ray:
+ * t and id = instance*8 + face, or -1 for a miss. */
+int pt_trace_rays(pt_ctx *ctx, int64_t n, int32_t rays_per_origin, const float *origins, const float *dirs,
+                  uint32_t k0, uint32_t k1, uint32_t vol_dim, float *t_out, int32_t *id_out);
+
 const char *pt_last_error(void);
 int pt_abi_version(void);
 int pt_device_count(void);   /* 0 when no HIP device is usable */

@@ -615,6 +615,26 @@ static inline int world_hit(const pto_scene *sc, const ray_t *r, hitrec *rec, rn
     return bvh_hit(sc, 0, r, (float)0.001, FLT_MAX, rec, rc);
 }
 
+void pto_world_hit_stream(const pto_scene *s, int64_t n, const float *origins, const float *dirs, uint32_t k0, uint32_t k1,
+                          uint32_t vol_dim, int32_t *hit, float *t, int32_t *inst)
+{
+    for (int64_t i = 0; i < n; i++) {
+        rngctx rc;
+        memset(&rc, 0, sizeof(rc));
+        rc.mode = PTO_MODE_STREAM;
+        rc.key.k0 = k0; rc.key.k1 = k1;
+        rc.vol_dim_base = vol_dim;
+        ray_t r;
+        r.A = V(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        r.B = V(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+        hitrec rec;
+        memset(&rec, 0, sizeof(rec));
+        hit[i] = world_hit(s, &r, &rec, &rc);
+        t[i] = hit[i] ? rec.t : 0.0f;
+        inst[i] = hit[i] ? rec.inst : -1;
+    }
+}
+
 /* BVH build: bvh.h:71-175.  qsort here is glibc's merge sort (msort.c): top-down, left run
  * element taken iff cmp <= 0; the comparator returns only -1/+1 (never 0). */
 typedef struct { pto_scene *sc; int axis; } sortctx;

@@ -115,6 +115,11 @@ void pto_render_stream(const pto_scene *s, const pto_config *cfg, uint32_t seed,
 void pto_sample_stream(const pto_scene *s, const pto_config *cfg, uint32_t seed, int i, int j, int sample,
                        float rgb[3], pto_counters *ctr);
 
+/* STREAM mode World::hit (world.h:17-20; t range (0.001, FLT_MAX) as in integrator.h:193) for n explicit rays.  k0, k1 =
+ * stream key, vol_dim = dimension of volume ordinal 0.  out: hit flag, t, instance index per ray. */
+void pto_world_hit_stream(const pto_scene *s, int64_t n, const float *origins, const float *dirs, uint32_t k0, uint32_t k1,
+                          uint32_t vol_dim, int32_t *hit, float *t, int32_t *inst);
+
 /* portable math used by stream mode (exposed for tests against libm) */
 void ptm_sincos_2pi(float r, float *s, float *c);
 float ptm_cbrtf(float x);

@@ -94,6 +94,8 @@ def lib():
         L.pto_render_stream.argtypes = [C.c_void_p, C.POINTER(Config), C.c_uint32] + [C.c_int] * 7 + [fp, C.POINTER(Counters)]
         L.pto_sample_stream.argtypes = [C.c_void_p, C.POINTER(Config), C.c_uint32, C.c_int, C.c_int, C.c_int, fp,
                                         C.POINTER(Counters)]
+        L.pto_world_hit_stream.argtypes = [C.c_void_p, C.c_int64, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.POINTER(C.c_int32), fp, C.POINTER(C.c_int32)]
         L.ptm_sincos_2pi.argtypes = [C.c_float, fp, fp]
         L.ptm_cbrtf.argtypes = [C.c_float]
         L.ptm_cbrtf.restype = C.c_float
@@ -229,6 +231,17 @@ class Scene:
         lib().pto_render_stream(self._h, C.byref(cfg), seed, rect[0], rect[1], rect[2], rect[3], s0, s1, threads,
                                 _fp(fb), C.byref(ctr))
         return fb, ctr.as_dict()
+
+    def world_hit_stream(self, origins, dirs, k0=0, k1=0, vol_dim=8):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        hit = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        inst = np.zeros(n, np.int32)
+        ip = C.POINTER(C.c_int32)
+        lib().pto_world_hit_stream(self._h, n, _fp(o), _fp(d), k0, k1, vol_dim, hit.ctypes.data_as(ip), _fp(t), inst.ctypes.data_as(ip))
+        return hit, t, inst
 
     def sample_stream(self, cfg: Config, i, j, s, seed=0):
         rgb = np.zeros(3, np.float32)

@@ -91,7 +91,7 @@ class HostConfig(C.Structure):
 EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
-           "pt_read_last_batch_radiance", "pt_last_error", "pt_abi_version", "pt_device_count",
+           "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
            "pth_config_from_file", "pth_config_from_json", "pth_scene_from_file", "pth_scene_from_json",
            "pth_scene_desc", "pth_scene_free", "pth_spiral_tiles", "pth_write_ppm", "pth_main"]
 
@@ -128,6 +128,7 @@ def lib():
     L.pt_set_profiling.argtypes = [vp, C.c_int]
     L.pt_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     L.pt_read_last_batch_radiance.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.pt_trace_rays.argtypes = [vp, C.c_int64, C.c_int32, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_int32)]
     L.pt_last_error.restype = C.c_char_p
     L.pt_abi_version.restype = C.c_int
     L.pt_device_count.restype = C.c_int
@@ -300,6 +301,19 @@ class Renderer:
         _check(lib().pt_read_last_batch_radiance(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), n, C.byref(got)),
                "pt_read_last_batch_radiance")
         return out[:got.value]
+
+    def trace_rays(self, origins, dirs, k0=0, k1=0, vol_dim=8):
+        """World::hit for explicit rays (validation hook).  dirs.shape = (n, 3) or (n, 4, 3)."""
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        nr = 1 if d.ndim == 2 else d.shape[1]
+        t = np.zeros(n * nr, np.float32)
+        ids = np.zeros(n * nr, np.int32)
+        fpp = C.POINTER(C.c_float)
+        _check(lib().pt_trace_rays(self._h, n, nr, o.ctypes.data_as(fpp), d.ctypes.data_as(fpp), k0, k1, vol_dim,
+                                   t.ctypes.data_as(fpp), ids.ctypes.data_as(C.POINTER(C.c_int32))), "pt_trace_rays")
+        return (t, ids) if nr == 1 else (t.reshape(n, nr), ids.reshape(n, nr))
 
     def device_framebuffer_ptr(self) -> int:
         return lib().pt_device_framebuffer(self._h)

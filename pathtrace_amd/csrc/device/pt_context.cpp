@@ -20,6 +20,8 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s);
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
+void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
+                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s);
 }  // namespace ptd
 
 using namespace ptd;
@@ -673,6 +675,30 @@ extern "C" int pt_get_counters(pt_ctx *c, pt_counters *out)
     out->term_miss = d.term_miss; out->term_rr = d.term_rr; out->term_emitter = d.term_emitter;
     out->term_pdf = d.term_pdf; out->term_bounce_limit = d.term_bounce_limit;
     return 0;
+}
+
+extern "C" int pt_trace_rays(pt_ctx *c, int64_t n, int32_t nr, const float *origins, const float *dirs, uint32_t k0, uint32_t k1,
+                             uint32_t vol_dim, float *t_out, int32_t *id_out)
+{
+    if (!c || n < 1 || (nr != 1 && nr != 4) || !origins || !dirs || !t_out || !id_out) { set_err("pt_trace_rays: bad argument"); return -1; }
+    if (pt_wait(c)) return -1;
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int *d_i = nullptr;
+    const size_t nray = (size_t)n * nr;
+    int rc = -1;
+    do {
+        if (hipMalloc((void **)&d_o, (size_t)n * 12) != hipSuccess || hipMalloc((void **)&d_d, nray * 12) != hipSuccess ||
+            hipMalloc((void **)&d_t, nray * 4) != hipSuccess || hipMalloc((void **)&d_i, nray * 4) != hipSuccess) { set_err("pt_trace_rays: hipMalloc failed"); break; }
+        if (hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_d, dirs, nray * 12, hipMemcpyHostToDevice) != hipSuccess) { set_err("pt_trace_rays: upload failed"); break; }
+        launch_trace(c->S, n, nr, d_o, d_d, k0, k1, vol_dim, d_t, d_i, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { set_err("pt_trace_rays: kernel failed"); break; }
+        if (hipMemcpy(t_out, d_t, nray * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(id_out, d_i, nray * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("pt_trace_rays: download failed"); break; }
+        rc = 0;
+    } while (0);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_i);
+    return rc;
 }
 
 extern "C" void *pt_device_framebuffer(pt_ctx *c) { return c ? (void *)c->st.fb : nullptr; }

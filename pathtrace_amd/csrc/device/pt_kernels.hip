@@ -1039,6 +1039,36 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// trace: World::hit for caller-supplied rays (pt_trace_rays), same traversal as k_extend / k_connect
+// ------------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restrict__ t_ops, long long n, const float *__restrict__ org,
+                                                    const float *__restrict__ dir, uint32_t k0, uint32_t k1, uint32_t vol_dim,
+                                                    float *t_out, int *id_out)
+{
+    S.ops = t_ops;
+    extern __shared__ float2 stack[];
+    const long long i = (long long)blockIdx.x * PT_BLOCK + threadIdx.x;
+    const bool valid = i < n;
+    const long long j = valid ? i : 0;
+    const v3 A = V(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
+    v3 B[NR];
+    uint32_t vd[NR];
+    float t[NR];
+    int id[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
+        vd[r] = vol_dim + (uint32_t)r * 16u;
+    }
+    world_hit_n<NR>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 // at most 4096 workgroups per launch (256 CUs x 8 resident x 2: measured better balanced than 2048), few enough to dispatch quickly
@@ -1070,6 +1100,14 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
     else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
     else hipLaunchKernelGGL(k_connect<0>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+}
+void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
+                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s)
+{
+    const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
+    const size_t lds = (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
+    if (nr == 4) hipLaunchKernelGGL(k_trace<4>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
+    else hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {

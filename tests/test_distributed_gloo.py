@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The GPU kernels cannot run here, so the oracle (stream mode: the bit-level twin
+of the device path) stands in as the renderer of each rank; what is under test is the product's distributed plumbing
+(pathtrace_amd/distributed.py): NaiveSpiral tile ownership k mod N covers the film exactly once, and the one sum-reduce
+of the RGBA framebuffer reproduces the single-process image BIT FOR BIT (disjoint ownership => the reduce adds zeros)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, scene_path
+
+W, H, SPP, TILE = 96, 54, 3, 32
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pt_oracle
+    from pathtrace_amd.distributed import reduce_framebuffer, tiles_for_rank
+
+    osc = pt_oracle.Scene.from_json(scene_path("cornell_box"))
+    cfg = pt_oracle.make_config(W, H, SPP)
+    fb3 = np.zeros((H, W, 3), np.float32)
+    mine = tiles_for_rank(W, H, TILE, TILE, rank, world)
+    for (x0, y0, x1, y1) in mine:
+        osc.render_stream(cfg, seed=0, rect=(x0, y0, x1, y1), threads=2, fb=fb3)
+    fb = torch.zeros((H, W, 4), dtype=torch.float32)
+    fb[..., :3] = torch.from_numpy(fb3)
+    reduce_framebuffer(fb, dst=0)
+    counts = torch.tensor([len(mine)], dtype=torch.int64)
+    dist.all_reduce(counts)
+    if rank == 0:
+        np.save(out_path, fb.numpy())
+        assert counts.item() == 6   # 3 x 2 tiles of 32 at 96 x 54
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_partition_and_reduce_world2(tmp_path, oracle):
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    ref, _ = oracle.Scene.from_json(scene_path("cornell_box")).render_stream(oracle.make_config(W, H, SPP), seed=0, threads=2)
+    assert np.array_equal(got[..., :3].view(np.uint32), ref.view(np.uint32))
+    assert (got[..., 3] == 0).all()
+
+
+def test_tile_ownership_is_a_partition():
+    from pathtrace_amd.distributed import tiles_for_rank
+
+    for (w, h, world) in [(1920, 1080, 8), (3840, 2160, 8), (1920, 1080, 3), (200, 200, 2)]:
+        cover = np.zeros((h, w), np.int32)
+        n = []
+        for r in range(world):
+            t = tiles_for_rank(w, h, 128, 128, r, world)
+            n.append(len(t))
+            for x0, y0, x1, y1 in t:
+                cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all() and max(n) - min(n) <= 1
+    with pytest.raises(ValueError):
+        tiles_for_rank(64, 64, 32, 32, 2, 2)

@@ -1,0 +1,86 @@
+"""Unit-level parity of World::hit (world.h:17-20 -> bvh.h:31-69 -> aabb.h:34-53 / primitive.h:186-312 / volume.h:29-93)
+on the GPU against the oracle, on rays chosen to hit the corner cases the reference's comparison chains decide:
+zero and negative-zero direction components (1/0 slabs, t = +-inf), rays lying IN a rect's plane (0/0 -> NaN t, which the
+reference does not reject: SURVEY Q8), rays through exact edges and corners (xh == x0), origins on surfaces (t below
+0.001), NaN / huge / tiny components, and plain random rays.  The device traversal states those chains as sign tests of
+max/min "excess" values (pt_kernels.hip), so this is where a NaN or inf mismatch would show.
+
+Bar: hit/miss and instance identical, t bit-identical (any NaN == any NaN).  Both ray instantiations are exercised:
+1 ray per origin (k_extend's) and 4 rays sharing an origin (k_connect's).
+"""
+import numpy as np
+import pytest
+
+import pathtrace_amd as pt
+from conftest import SCENES, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def adversarial_rays(rng, n_random=60000):
+    F = np.float32
+    o, d = [], []
+    # random rays from inside and outside the box
+    o.append(rng.uniform(-100, 655, (n_random, 3)))
+    d.append(rng.normal(0, 1, (n_random, 3)) * rng.choice([1e-3, 1.0, 1e3], (n_random, 1)))
+    # axis-aligned and plane-aligned directions with +0 / -0 components
+    zs = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -277.5])
+    grid = np.array(np.meshgrid(zs, zs, zs)).reshape(3, -1).T
+    pts = np.array([[278, 278, 278], [277.5, 0.0, 277.5], [273, 554, 171], [0, 277.5, 277.5], [555, 277.5, 277.5],
+                    [277.5, 555, 277.5], [277.5, 277.5, 555], [212.5, 82.5, 147.5], [347.5, 165, 377.5], [278, 278, -750],
+                    [153, 554, 56], [393, 554, 286], [0, 0, 0], [555, 555, 555], [213, 554, 227]], np.float64)
+    for p in pts:
+        o.append(np.repeat(p[None], len(grid), 0))
+        d.append(grid)
+    # aim exactly at rect corners / edges / box corners from several origins
+    targets = np.array([[0, 0, 0], [555, 0, 0], [0, 555, 0], [555, 555, 555], [153, 554, 56], [393, 554, 56], [153, 554, 286],
+                        [393, 554, 286], [273, 554, 56], [555, 277.5, 0], [277.5, 0, 555], [130, 165, 65], [295, 165, 230],
+                        [265, 330, 295], [430, 330, 460], [212.5, 165, 147.5]], np.float64)
+    for src in pts[:10]:
+        o.append(np.repeat(src[None], len(targets), 0))
+        d.append(targets - src)
+        o.append(np.repeat(src[None], len(targets), 0))
+        d.append((targets - src) * 1e-4)
+    # pathological values
+    bad = np.array([[np.nan, 1, 1], [1, np.nan, 0], [np.inf, 1, 1], [1, -np.inf, 1], [1e38, 1e38, 1e38], [1e-38, 1e-38, 1e-38],
+                    [1e-45, 0, 1], [0, 0, 0], [-0.0, -0.0, -0.0], [3e38, -3e38, 1]])
+    for p in pts[:4]:
+        o.append(np.repeat(p[None], len(bad), 0))
+        d.append(bad)
+    o.append(np.array([[np.nan, 278, 278], [278, np.inf, 278], [1e30, 278, 278], [278, 278, -1e30]]))
+    d.append(np.array([[0, 0, 1], [0, -1, 0], [-1, 0, 0], [0, 0, 1]], np.float64))
+    return np.concatenate(o).astype(F), np.concatenate(d).astype(F)
+
+
+def same_t(a, b):
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)) | (a == b)
+
+
+@pytest.mark.parametrize("scene", SCENES)
+def test_world_hit_matches_oracle_on_adversarial_rays(oracle, scene):
+    rng = np.random.default_rng(7)
+    o, d = adversarial_rays(rng)
+    sc = pt.Scene(scene_path(scene), 64, 64)
+    r = pt.Renderer(sc, max_paths_in_flight=4096)
+    osc = oracle.Scene.from_json(scene_path(scene))
+    k0, k1, vd = 0x1234567, 0x89abcdef, 40
+    # one ray per origin
+    t, ids = r.trace_rays(o, d, k0, k1, vd)
+    hit, ot, inst = osc.world_hit_stream(o, d, k0, k1, vd)
+    ginst = np.where(ids >= 0, ids >> 3, -1)
+    assert np.array_equal(ginst, inst), f"{(ginst != inst).sum()} instance mismatches, first at {np.argmax(ginst != inst)}"
+    ok = same_t(t, ot) | (hit == 0)
+    assert ok.all(), f"{(~ok).sum()} t mismatches, first at {np.argmin(ok)}: {t[np.argmin(ok)]} vs {ot[np.argmin(ok)]}"
+    assert np.isnan(t[ids >= 0]).sum() > 0, "the ray set must contain in-plane rays that the reference reports as NaN-t hits"
+    assert (ids < 0).sum() > 1000 and (ids >= 0).sum() > 10000
+    # four rays sharing an origin: group consecutive directions (any grouping is a valid test)
+    n4 = (len(o) // 4) * 4
+    d4 = d[:n4].reshape(-1, 4, 3)
+    o4 = o[:n4:4]
+    t4, id4 = r.trace_rays(o4, d4, k0, k1, vd)
+    for k in range(4):
+        hit, ot, inst = osc.world_hit_stream(o4, d4[:, k], k0, k1, vd + 16 * k)
+        ginst = np.where(id4[:, k] >= 0, id4[:, k] >> 3, -1)
+        assert np.array_equal(ginst, inst), (k, (ginst != inst).sum())
+        assert (same_t(t4[:, k], ot) | (hit == 0)).all(), k
+    r.close()
