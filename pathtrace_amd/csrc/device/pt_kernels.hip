@@ -935,8 +935,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
     if (!v_is_nan(c)) lc = vadd(lc, c);
 }
 
-// NR = light_samples when it is 1, 2 or 4 (the rays of one hit share their origin and are traversed together),
-// NR = 0: any other count, one ray at a time.
+// NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
 template <int NR>
 __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
@@ -974,22 +973,24 @@ __global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__res
         v3 lc = V(0.0f, 0.0f, 0.0f);
         if (NR > 0) {
             constexpr int R = NR > 0 ? NR : 1;
-            v3 ldir[R], coef[R];
-            uint32_t vd[R];
-            float t[R];
-            int id[R];
+            for (uint32_t kg = 0; kg < L; kg += R) {   // light_samples is a multiple of R (launch_connect)
+                v3 ldir[R], coef[R];
+                uint32_t vd[R];
+                float t[R];
+                int id[R];
 #pragma unroll
-            for (int k = 0; k < R; k++) {
-                const float4 d = sq.d[(long long)k * P + pos];
-                const float2 e = sq.e[(long long)k * P + pos];
-                ldir[k] = V(d.x, d.y, d.z);
-                coef[k] = V(d.w, e.x, e.y);
-                vd[k] = base + NV + (uint32_t)k * (3u + NV) + 3u;
-            }
-            world_hit_n<R>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
-            if (valid) {
+                for (int k = 0; k < R; k++) {
+                    const float4 d = sq.d[(long long)(kg + k) * P + pos];
+                    const float2 e = sq.e[(long long)(kg + k) * P + pos];
+                    ldir[k] = V(d.x, d.y, d.z);
+                    coef[k] = V(d.w, e.x, e.y);
+                    vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
+                }
+                world_hit_n<R>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                if (valid) {
 #pragma unroll
-                for (int k = 0; k < R; k++) connect_contribution(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
+                    for (int k = 0; k < R; k++) connect_contribution(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
+                }
             }
         } else {
             for (uint32_t k = 0; k < L; k++) {
@@ -1094,7 +1095,11 @@ void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, 
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
     const int L = S.light_samples;
-    const int nr = (L == 1 || L == 2 || L == 4) ? L : 0;
+    // rays of one hit traversed together: 2 when light_samples is even, else 1.  Measured on cornell_box 1080p: 2 rays
+    // (80 VGPRs, 6 waves/SIMD) beat 4 rays (112 VGPRs, 4 waves/SIMD: more sharing, less latency hiding) and 1 ray.
+    static const int force = getenv("PATHTRACE_HIP_CONNECT_NR") ? atoi(getenv("PATHTRACE_HIP_CONNECT_NR")) : 0;
+    int nr = (L % 2 == 0) ? 2 : 1;
+    if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
     if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
     else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
