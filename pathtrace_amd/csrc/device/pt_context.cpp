@@ -148,6 +148,11 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
         op.push_slot = pending_push;
         pending_push = -1;
         memcpy(op.f, in.inv, 12 * sizeof(float));
+        {   // linear part exactly the identity (pure translation): the sweep then adds the translation and skips 30 multiplies
+            const float *m = in.inv;
+            op.slot = (m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f &&
+                       m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f) ? 1 : 0;
+        }
         switch (p.type) {
         case PT_PRIM_RECT:
             op.kind = p.plane == PT_PLANE_XY ? OP_LEAF_RECT_XY : (p.plane == PT_PLANE_YZ ? OP_LEAF_RECT_YZ : OP_LEAF_RECT_XZ);

@@ -59,7 +59,7 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
     // first half: everything an op needs FIRST (header + node box or instance matrix); it is prefetched one op ahead
     int32_t kind;
     int32_t a;           // ENTER: skip target;  LEAF: instance index (hit id = a*8 + face)
-    int32_t slot;        // COMBINE: short-stack slot
+    int32_t slot;        // COMBINE: short-stack slot;  LEAF: 1 if the instance's inverse linear part is exactly the identity
     int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
     float f[12];
     // second half: primitive parameters, needed only after the ray has been transformed

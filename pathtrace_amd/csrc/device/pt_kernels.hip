@@ -271,6 +271,11 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         cur_id[r] = -1;
         skip[r] = lane_valid ? 0 : 0x7fffffff;
     }
+    bool fin = true;
+#pragma unroll
+    for (int r = 0; r < NR; r++) fin = fin && isfinite(B[r].x) && isfinite(B[r].y) && isfinite(B[r].z);
+    fin = fin && isfinite(A.x) && isfinite(A.y) && isfinite(A.z);
+    const bool all_finite = __all(fin || !lane_valid);   // wave-uniform
     const int n_ops = S.n_ops;
     // Scalar-load pipeline: an op is two 64-byte halves.  The first half (header + box / matrix) of op pc+1 is
     // requested while op pc executes; the second half (primitive parameters) of op pc is requested at the top of
@@ -336,11 +341,17 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             // instance::hit primitive.h:298-312: local origin once, local direction per ray
             const float m[12] = {OPF(0), OPF(1), OPF(2), OPF(3), OPF(4), OPF(5), OPF(6), OPF(7), OPF(8), OPF(9), OPF(10), OPF(11)};
             const float q0[3] = {OPF(12), OPF(13), OPF(14)}, q1[3] = {OPF(15), OPF(16), OPF(17)};
-            const v3 Al = xf_point(m, A);
+            // Pure translation (op_slot = 1): for FINITE ray components t + ((1*x + 0*y) + 0*z) == t + x and
+            // (1*x + 0*y) + 0*z == x; only the sign of a zero component can differ, which no comparison below can see
+            // (+-inf t is rejected either way, 0/0 is NaN either way).  A wave holding any non-finite ray (0*inf = NaN
+            // would spread across components) takes the general path.
+            const bool ident = (op_slot != 0) && all_finite;
+            const v3 Al = ident ? V(m[3] + A.x, m[7] + A.y, m[11] + A.z) : xf_point(m, A);
+#define XF_DIR(b) (ident ? (b) : xf_linear(m, (b)))
             if (kind == OP_LEAF_BOX) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(m, B[r]);
+                    const v3 Bl = XF_DIR(B[r]);
                     float t;
                     int face;
                     box_hit_shared(q0, q1, Al, Bl, T_MIN, T_MAX, t, face);
@@ -351,7 +362,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             } else if (kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(m, B[r]);
+                    const v3 Bl = XF_DIR(B[r]);
                     float t1v, t2v;
                     int f1, f2;
                     box_hit_shared(q0, q1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f1);
@@ -374,7 +385,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 const float c = vdot(oc, oc) - q1[0] * q1[0];
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(m, B[r]);
+                    const v3 Bl = XF_DIR(B[r]);
                     const float a = vdot(Bl, Bl);
                     const float b = vdot(oc, Bl);
                     const float disc = b * b - a * c;
@@ -392,7 +403,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 const float num = q1[1] - opl;
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
-                    const v3 Bl = xf_linear(m, B[r]);
+                    const v3 Bl = XF_DIR(B[r]);
                     float t, e;
                     if (kind == OP_LEAF_RECT_XY) e = rect_excess<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
                     else if (kind == OP_LEAF_RECT_YZ) e = rect_excess<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
@@ -403,6 +414,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 }
             }
         }
+#undef XF_DIR
 #undef OPF
         if (jumped) w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc + 1]);   // rare: the prefetched op is not the next one
         else w0 = nxt;
