@@ -40,7 +40,8 @@ typedef struct pt_material {   /* material.h: lambertian / metal / diffuse_light
     float alpha;               /* constant_texture::a */
     float power;               /* diffuse_light::power (material.h:243) */
     int32_t two_sided;         /* diffuse_light::two_sided */
-    float fuzz, ior;           /* metal / dielectric (not yet executed on device; see pt_create) */
+    float fuzz, ior;           /* metal / dielectric: carried for completeness; neither influences NEEIterative's radiance
+                                  (metal is cosine-diffuse material.h:99-108, a dielectric path ends after its NEE) */
 } pt_material;
 
 typedef struct pt_primitive {

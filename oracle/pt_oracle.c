@@ -701,7 +701,6 @@ pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *
     sc->cam = *cam;
     sc->background = V(background[0], background[1], background[2]);
     for (int i = 0; i < nmat; i++) {
-        if (mats[i].type == PTO_MAT_DIELECTRIC) goto fail; /* not yet restated */
         sc->mats[i].type = mats[i].type;
         sc->mats[i].color = V(mats[i].color[0], mats[i].color[1], mats[i].color[2]);
         sc->mats[i].alpha = mats[i].alpha;
@@ -951,6 +950,13 @@ static v3 material_generate(const mat_t *m, v3 normal, rngctx *rc, uint32_t dim)
         float x = c * sqrtf(r2);
         float y = s * sqrtf(r2);
         return onb_local(&uvw, V(x, y, z));
+    }
+    if (m->type == PTO_MAT_DIELECTRIC) {
+        /* dielectric::generate material.h:125-166: reflect / refract / schlick, then ONE draw picks between them.  Its
+           value() is void_pdf = 0 (material.h:167-170), so NEEIterative breaks at scatter_pdf_s < 1e-7
+           (integrator.h:301-304) before the direction is ever used: only the draw is observable (MT stream position). */
+        (void)rnd(rc, dim + 0);
+        return V(0, 0, 0);
     }
     return random_in_unit_sphere(rc, dim); /* isotropic material.h:267-270 (and void_pdf) */
 }

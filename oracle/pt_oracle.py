@@ -280,9 +280,9 @@ def ref_run(params: sp.SceneParams, mode: str, args, workdir: str):
     return out.stdout.decode(errors="replace")
 
 
-def ref_render(params, cfg: Config, workdir: str):
+def ref_render(params, cfg: Config, workdir: str, ppm_path: str = None):
     out = os.path.join(workdir, "fb.f32")
-    txt = ref_run(params, "render", _cfg_args(cfg) + [out], workdir)
+    txt = ref_run(params, "render", _cfg_args(cfg) + [out] + ([ppm_path] if ppm_path else []), workdir)
     rays = int([l for l in txt.splitlines() if l.startswith("REF_RAYS")][0].split()[1])
     fb = np.fromfile(out, np.float32).reshape(cfg.height, cfg.width, 3)
     return fb, rays

@@ -14,7 +14,8 @@
 // Modes (argv[2]):
 //   rng N out.f64                     first N random_double() values after static init
 //   tables out.txt                    matrices / bboxes / BVH topology / camera / lights
-//   render  <cfg...> out.f32          Tiled + NEEIterative through start_render/sync/finalize
+//   render  <cfg...> out.f32 [out.ppm] Tiled + NEEIterative through start_render/sync/finalize; the optional PPM is
+//                                     the file Renderer::output writes (output_to_file renderer.h:24-55)
 //   samples <cfg...> N out.f32        first N camera samples in Tiled::compute order:
 //                                     u v  ray(7)  col(3)  rays(1)  = 13 floats / sample
 //   hits    <cfg...> N out.f32        world->hit of the first N camera rays:
@@ -301,7 +302,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "missing cfg\n");
         return 2;
     }
-    Config config = make_config(argv + 3, "/dev/null");
+    Config config = make_config(argv + 3, (mode == "render" && argc >= 15) ? argv[14] : "/dev/null");
     b.world->config = config; // main.cpp:139
     camera cam = make_camera(b, config);
     if (mode == "render")

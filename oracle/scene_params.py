@@ -171,7 +171,8 @@ class _Builder:
                 fz = f32(data.get("roughness", 0.0))
                 m = Material(MAT_METAL, col, fuzz=fz if fz < 1 else F(1), json_type="metal")
             elif mtype == "dielectric":
-                m = Material(MAT_DIELECTRIC, ior=f32(data["ior"]) if "ior" in data else F(1.450),
+                # attenuation of dielectric::scatter is (1,1,1) (material.h:118-124); "color" is announced as unsupported
+                m = Material(MAT_DIELECTRIC, (F(1), F(1), F(1)), ior=f32(data["ior"]) if "ior" in data else F(1.450),
                              json_type="dielectric")
             elif mtype == "diffuse_light":
                 power = f32(data["power"]) if "power" in data else F(1.0)

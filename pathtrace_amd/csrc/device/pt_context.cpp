@@ -211,11 +211,6 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     std::vector<DMat> mats(sc->n_materials);
     for (int i = 0; i < sc->n_materials; i++) {
         const pt_material &m = sc->materials[i];
-        if (m.type == PT_MAT_DIELECTRIC) {
-            set_err("pt_create: material %d is dielectric, which the device path does not implement yet "
-                    "(outside the BASELINE scenes; SURVEY.md 8f-2)", i);
-            return -1;
-        }
         if (m.type < 0 || m.type > PT_MAT_ISOTROPIC) { set_err("pt_create: bad material type %d", m.type); return -1; }
         DMat d{};
         d.type = m.type; d.r = m.color[0]; d.g = m.color[1]; d.b = m.color[2];

@@ -573,6 +573,9 @@ DEVI v3 material_generate(int type, v3 normal, uint32_t k0, uint32_t k1, uint32_
         float y = s * sqrtf(r2);
         return onb_local(uvw, V(x, y, z));
     }
+    // dielectric::generate (material.h:125-166) picks reflect / refract with one draw, but dielectric::value is 0, so
+    // the path ends at scatter_pdf_s < 1e-7 (integrator.h:301-304) before the direction is used: nothing to compute
+    if (type == 2) return V(0.0f, 0.0f, 0.0f);
     return random_in_unit_sphere(k0, k1, dim);
 }
 DEVI v3 material_emitted(const DMat &m, v3 ray_dir, v3 normal)
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
 // material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
 // continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
@@ -821,6 +824,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_shade(DScene S, const DOp *__restr
                     if (vdot(B, hi.n) < 0) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
                     else att = V(0.0f, 0.0f, 0.0f);
                 } else if (m.type == 1) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
+                else if (m.type == 2) att = V(1.0f, 1.0f, 1.0f);   // dielectric::scatter material.h:118-124
                 else if (m.type == 3) did_scatter = false;
                 else if (m.type == 4) att = V(m.r, m.g, m.b);
                 const float cos_i = fabsf(vdot(vunit(B), vunit(hi.n)));

@@ -9,7 +9,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
+SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]   # the BASELINE configs
+# beyond BASELINE: sphere lights + metal, dielectric, a room-filling volume
+EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
+ALL_SCENES = SCENES + EXTRA_SCENES
 
 
 def pytest_configure(config):

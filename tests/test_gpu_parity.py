@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import pathtrace_amd as pt
-from conftest import SCENES, scene_path
+from conftest import ALL_SCENES, EXTRA_SCENES, SCENES, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def assert_counters(gc, oc, what):
         assert gc[g] == oc[o], f"{what}: counter {g}: gpu {gc[g]} oracle {oc[o]}"
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", ALL_SCENES)
 def test_bit_exact_vs_oracle_stream_64x64x4(oracle, scene):
     w, h, spp = 64, 64, 4
     ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=0)
@@ -73,6 +73,16 @@ def test_bit_exact_config1_size_200x200x16(oracle, scene):
     w, h, spp = 200, 200, 16
     ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=0)
     gpu, gc = gpu_render(scene, w, h, spp)
+    assert_bit_identical(gpu, ref, scene)
+    assert_counters(gc, oc, scene)
+
+
+@pytest.mark.parametrize("scene", EXTRA_SCENES)
+def test_bit_exact_extra_scenes_16x9(oracle, scene):
+    # beyond BASELINE: sphere lights with cone sampling + metal, dielectric spheres, a room-filling volume
+    w, h, spp = 160, 90, 8
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=5)
+    gpu, gc = gpu_render(scene, w, h, spp, seed=5)
     assert_bit_identical(gpu, ref, scene)
     assert_counters(gc, oc, scene)
 
@@ -183,11 +193,13 @@ def test_async_protocol_and_errors():
     r.clear()
     assert r.framebuffer().sum() == 0 and r.counters()["rays"] == 0
     r.close()
-    # unsupported material is refused loudly, not silently approximated
+    # unsupported scene features are refused loudly at load, not silently approximated
     import json
     s = json.load(open(scene_path("cornell_box")))
-    s["materials"].append({"id": "glass", "type": "dielectric", "data": {"ior": 1.5}})
-    s["instances"][5]["primitive"] = {"id": "gbox"}
-    s["primitives"].append({"id": "gbox", "type": "box", "material": {"id": "glass"}, "size": [165, 165, 165]})
+    s["textures"] = [{"id": "n", "type": "perlin", "data": {"scale": 1.0}}]
+    with pytest.raises(pt.PathtraceError):
+        pt.Scene(text=json.dumps(s), width=64, height=64)
+    s = json.load(open(scene_path("cornell_box_with_volume")))
+    s["primitives"][2]["primitive"] = "white_wall"          # a volume whose boundary is a rect: not implemented on device
     with pytest.raises(pt.PathtraceError):
         pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))

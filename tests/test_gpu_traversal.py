@@ -12,14 +12,28 @@ import numpy as np
 import pytest
 
 import pathtrace_amd as pt
-from conftest import SCENES, scene_path
+from conftest import ALL_SCENES, scene_path
 
 pytestmark = pytest.mark.gpu
 
 
-def adversarial_rays(rng, n_random=60000):
+def adversarial_rays(rng, bbox, n_random=60000):
     F = np.float32
     o, d = [], []
+    # rays aimed at random points of the scene's own bounding box (so that every scene gets plenty of hits), from
+    # inside and around it, plus axis-aligned +-0 directions from points inside it
+    mn, mx = bbox[:3].astype(np.float64), bbox[3:].astype(np.float64)
+    ext = mx - mn
+    src = mn - 0.5 * ext + rng.random((20000, 3)) * 2.0 * ext
+    dst = mn + rng.random((20000, 3)) * ext
+    o.append(src)
+    d.append((dst - src) * rng.choice([1e-3, 1.0, 37.0], (20000, 1)))
+    ins = mn + rng.random((12, 3)) * ext
+    zs0 = np.array([0.0, -0.0, 1.0, -1.0, 0.25])
+    g0 = np.array(np.meshgrid(zs0, zs0, zs0)).reshape(3, -1).T
+    for p in ins:
+        o.append(np.repeat(p[None], len(g0), 0))
+        d.append(g0)
     # random rays from inside and outside the box
     o.append(rng.uniform(-100, 655, (n_random, 3)))
     d.append(rng.normal(0, 1, (n_random, 3)) * rng.choice([1e-3, 1.0, 1e3], (n_random, 1)))
@@ -56,11 +70,11 @@ def same_t(a, b):
     return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)) | (a == b)
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", ALL_SCENES)
 def test_world_hit_matches_oracle_on_adversarial_rays(oracle, scene):
     rng = np.random.default_rng(7)
-    o, d = adversarial_rays(rng)
     sc = pt.Scene(scene_path(scene), 64, 64)
+    o, d = adversarial_rays(rng, sc.nodes()[0][0])
     r = pt.Renderer(sc, max_paths_in_flight=4096)
     osc = oracle.Scene.from_json(scene_path(scene))
     k0, k1, vd = 0x1234567, 0x89abcdef, 40
@@ -71,8 +85,9 @@ def test_world_hit_matches_oracle_on_adversarial_rays(oracle, scene):
     assert np.array_equal(ginst, inst), f"{(ginst != inst).sum()} instance mismatches, first at {np.argmax(ginst != inst)}"
     ok = same_t(t, ot) | (hit == 0)
     assert ok.all(), f"{(~ok).sum()} t mismatches, first at {np.argmin(ok)}: {t[np.argmin(ok)]} vs {ot[np.argmin(ok)]}"
-    assert np.isnan(t[ids >= 0]).sum() > 0, "the ray set must contain in-plane rays that the reference reports as NaN-t hits"
-    assert (ids < 0).sum() > 1000 and (ids >= 0).sum() > 10000
+    if scene.startswith("cornell_box"):
+        assert np.isnan(t[ids >= 0]).sum() > 0, "the ray set must contain in-plane rays that the reference reports as NaN-t hits"
+    assert (ids < 0).sum() > 100 and (ids >= 0).sum() > 5000
     # four rays sharing an origin: group consecutive directions (any grouping is a valid test)
     n4 = (len(o) // 4) * 4
     d4 = d[:n4].reshape(-1, 4, 3)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import pathtrace_amd as pt
-from conftest import GOLD, ROOT, SCENES, scene_path
+from conftest import ALL_SCENES, GOLD, ROOT, SCENES, scene_path
 from test_oracle_golden import _parse_tables, bits
 
 
@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.pt_abi_version() == 1
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", ALL_SCENES)
 def test_flattened_scene_matches_reference_tables(oracle, scene):
     gold = _parse_tables(os.path.join(GOLD, f"tables_{scene}.txt"))
     sc = pt.Scene(scene_path(scene), 1920, 1080)
@@ -61,6 +61,8 @@ def test_flattened_scene_matches_reference_tables(oracle, scene):
             assert tuple(np.float32(x) for x in dp.rect) == tuple(p.rect) and (dp.plane, bool(dp.flipped)) == (p.plane, p.flipped)
         elif p.type == pt.PRIM_BOX:
             assert tuple(np.float32(x) for x in dp.p0) == tuple(p.p0) and tuple(np.float32(x) for x in dp.p1) == tuple(p.p1)
+        elif p.type == pt.PRIM_SPHERE:
+            assert tuple(np.float32(x) for x in dp.center) == tuple(p.center) and np.float32(dp.radius) == p.radius
         elif p.type == pt.PRIM_VOLUME:
             assert (dp.boundary, np.float32(dp.density), dp.phase_material) == (p.boundary, p.density, p.phase_mat)
 
@@ -122,6 +124,20 @@ def test_scene_errors_are_loud():
     bad["instances"][0]["primitive"]["id"] = "nope"
     with pytest.raises(pt.PathtraceError):
         pt.Scene(text=json.dumps(bad), width=10, height=10)
+
+
+@pytest.mark.parametrize("scene", ALL_SCENES)
+def test_film_output_matches_reference_ppm(tmp_path, scene):
+    # F6: the reference's own P6 file (calculate_luminance helpers.h:146-168 -> tonemap_uncharted tonemap.h:4-24 -> to_srgb
+    # helpers.h:78-93 -> output_to_file renderer.h:24-55, with film.exposure holding the "gamma" value 2.2 per the
+    # config.h:24-25 swap) for the reference's own framebuffer.  Byte-identical, header included.
+    fb = np.load(os.path.join(GOLD, f"fb_{scene}_64x64x4.npy"))
+    gold = open(os.path.join(GOLD, f"ppm_{scene}_64x64x4.ppm"), "rb").read()
+    out = tmp_path / "o.ppm"
+    pt.write_ppm(str(out), fb, samples=4, exposure_field=2.2)
+    got = out.read_bytes()
+    assert len(got) == len(gold)
+    assert got == gold, f"{sum(a != b for a, b in zip(got, gold))} of {len(gold)} bytes differ"
 
 
 def test_ppm_writer(tmp_path):

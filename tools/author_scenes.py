@@ -110,6 +110,73 @@ scenes["cornell_box_with_volume"] = {
     + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
 }
 
+# ---- scenes beyond the BASELINE configs (sphere lights, metal, dielectric, a room-filling volume) ----
+def cam(frm, at, fov, focus):
+    return {"look_from": list(frm), "look_at": list(at), "fov": fov, "aperture": 0.0, "dist_to_focus": focus}
+
+
+def direct_notransform(prim):
+    return {"type": "direct", "primitive": prim}
+
+
+scenes["light_test"] = {
+    "camera": cam((0.0, 80.0, -80.0), (0.0, 0.0, 0.0), 40.0, 40.0),
+    "world": {"color": [0.01, 0.01, 0.01]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("white", (0.7, 0.7, 0.7)),
+                  {"id": "metal1", "type": "metal", "data": {"color": [0.9, 0.9, 0.9], "roughness": 0.1}},
+                  {"id": "metal2", "type": "metal", "data": {"color": [0.9, 0.9, 0.9], "roughness": 0.2}},
+                  {"id": "metal3", "type": "metal", "data": {"color": [0.9, 0.9, 0.9], "roughness": 0.3}},
+                  light_mat((25.0, 25.0, 25.0))],
+    "primitives": [{"id": "wall", "type": "rect", "material": {"id": "white"}, "size": [80, 80]}],
+    "instances": [
+        {"type": "ref", "primitive": {"id": "wall"}},
+        ref("wall", rotate=[-0.5, 0.0, 0.0], translate=[0.0, 40.0, 40.0]),
+        direct({"type": "sphere", "material": {"id": "light"}, "radius": 2}, translate=[-15, 20.0, 4.0]),
+        direct({"type": "sphere", "material": {"id": "light"}, "radius": 1.5}, translate=[-5, 20.0, 4.0]),
+        direct({"type": "sphere", "material": {"id": "light"}, "radius": 1}, translate=[5, 20.0, 4.0]),
+        direct({"type": "sphere", "material": {"id": "light"}, "radius": 0.5}, translate=[15, 20.0, 4.0]),
+        direct({"type": "rect", "material": {"id": "metal3"}, "size": [40, 4.8]}, rotate=[-0.0922222, 0.0, 0.0], translate=[0, 3, 0]),
+        direct({"type": "rect", "material": {"id": "metal2"}, "size": [40, 4]}, rotate=[-0.155, 0.0, 0.0], translate=[0, 4, 6]),
+        direct({"type": "rect", "material": {"id": "metal1"}, "size": [40, 4]}, rotate=[-0.2177777, 0.0, 0.0], translate=[0, 10, 8]),
+    ],
+}
+
+scenes["three_orbs"] = {
+    "camera": cam((0.0, 20.0, -40.0), (0.0, 0.0, 0.0), 40.0, 40.0),
+    "world": {"color": [0.0, 0.0, 0.0]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.45, 0.15)), lambertian("white", (0.7, 0.7, 0.7)),
+                  {"id": "metal", "type": "metal", "data": {"color": [0.9, 0.9, 0.9]}},
+                  {"id": "glass", "type": "dielectric", "data": {"color": [0.9, 0.9, 0.9]}},
+                  light_mat((25.0, 25.0, 25.0))],
+    "primitives": [],
+    "instances": [
+        direct_notransform({"type": "rect", "material": {"id": "white"}, "size": [80, 80]}),
+        direct({"type": "rect", "material": {"id": "light"}, "size": [5, 5]}, translate=[0, 20.0, 10]),
+        direct({"type": "sphere", "material": {"id": "green"}, "radius": 4}, translate=[-10, 4, 0]),
+        direct({"type": "sphere", "material": {"id": "glass"}, "radius": 4}, translate=[0, 4, 0]),
+        direct({"type": "sphere", "material": {"id": "metal"}, "radius": 4}, translate=[10, 4, 0]),
+    ],
+}
+
+scenes["cornell_box_with_volume2"] = {
+    "camera": camera(-700.0),
+    "world": {"color": [0.0, 0.0, 0.0]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.45, 0.15)), lambertian("red", (0.65, 0.05, 0.05)),
+                  lambertian("white", (0.73, 0.73, 0.73)),
+                  {"id": "isotropic", "type": "isotropic", "data": {"color": [0.93, 0.93, 0.93], "density": 0.0004}},
+                  light_mat((1.0, 1.0, 1.0))],
+    "primitives": [
+        BASE_PRIMS[0],
+        {"id": "box", "type": "box", "size": [555, 555, 555]},
+        {"id": "fog", "type": "volume", "primitive": "box", "density": 0.001, "color": [0.9, 0.9, 0.9]},
+    ],
+    "instances": walls([{"skip": True, **ref("box", **SHORT_BOX_XF)}, ref("fog", translate=[277.5, 277.5, 277.5])])
+    + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
+}
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for name, sc in scenes.items():

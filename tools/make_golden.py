@@ -10,6 +10,7 @@ are data (inputs + expected outputs); no reference source is stored.
   F3  tables_<scene>.txt         fwd/inv matrices, bboxes, BVH topology, lights, camera (hex floats)
   F4  samples_<scene>.npy        first 4096 camera samples: u v ray(7) col(3) rays
   F5  hits_<scene>.npy           world->hit of the first 4096 camera rays: hit t p n inst
+  F6  ppm_<scene>_64x64x4.ppm    the reference's P6 film output (tonemap + sRGB) for framebuffer fb_<scene>_64x64x4
 """
 import json
 import os
@@ -25,6 +26,8 @@ from oracle import scene_params as sp  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
+# scenes beyond the BASELINE configs: sphere lights + metal, dielectric, a room-filling volume
+EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
 
 # name -> (width, height, samples, kwargs)
 CONFIGS = {
@@ -50,7 +53,7 @@ def main():
         out = os.path.join(d, "rng.f64")
         po.ref_run(sp.load_scene_params(os.path.join(ROOT, "scenes", SCENES[0] + ".json")), "rng", ["4096", out], d)
         np.save(os.path.join(GOLD, "rng_after_static_init.npy"), np.fromfile(out, np.float64))
-        for scene in SCENES:
+        for scene in SCENES + EXTRA_SCENES:
             P = sp.load_scene_params(os.path.join(ROOT, "scenes", scene + ".json"))
             t = os.path.join(d, "tables.txt")
             po.ref_run(P, "tables", [t, "1920", "1080"], d)
@@ -58,10 +61,16 @@ def main():
                 g.write(f.read())
             manifest["tables"].append({"scene": scene, "file": f"tables_{scene}.txt", "camera_aspect": [1920, 1080]})
             for cname, (w, h, spp, kw) in CONFIGS.items():
-                if cname not in FULL_ONLY and cname != "64x64x4" and scene not in VARIANT_SCENES:
+                if scene in EXTRA_SCENES and cname not in ("64x64x4", "96x54x8_t32"):
+                    continue
+                if cname not in FULL_ONLY and cname != "64x64x4" and scene not in VARIANT_SCENES and scene not in EXTRA_SCENES:
                     continue
                 cfg = po.make_config(w, h, spp, **kw)
-                fb, rays = po.ref_render(P, cfg, d)
+                ppm = os.path.join(d, "out.ppm") if cname == "64x64x4" else None
+                fb, rays = po.ref_render(P, cfg, d, ppm)
+                if ppm:   # F6: the reference's own film output for this framebuffer (renderer.h:24-55)
+                    with open(ppm, "rb") as f, open(os.path.join(GOLD, f"ppm_{scene}_{cname}.ppm"), "wb") as g:
+                        g.write(f.read())
                 fn = f"fb_{scene}_{cname}.npy"
                 np.save(os.path.join(GOLD, fn), fb)
                 manifest["framebuffers"].append({"scene": scene, "config": cname, "file": fn, "width": w, "height": h,
