@@ -263,6 +263,13 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         memcpy(d.fwd, p.fwd, sizeof d.fwd);
         d.prim = p.primitive;
         d.vol_ordinal = (prims[p.primitive].type == PT_PRIM_VOLUME) ? nvol++ : -1;
+        {
+            auto is_ident = [](const float *m) {
+                return m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f &&
+                       m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f;
+            };
+            d.ident = is_ident(p.inv) && is_ident(p.fwd);
+        }
         insts[i] = d;
     }
     std::vector<int32_t> lights(sc->lights, sc->lights + sc->n_lights);

@@ -29,7 +29,8 @@ struct DInst {           // 112 bytes
     float fwd[12];       // local -> world
     int32_t prim;
     int32_t vol_ordinal; // ordinal among volume instances (stream RNG dimension slot), -1 otherwise
-    int32_t pad[2];
+    int32_t ident;       // 1 if the linear parts of inv and fwd are exactly the identity (pure translation)
+    int32_t pad[1];
 };
 struct DMat {            // 32 bytes
     int32_t type;

@@ -890,6 +890,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             qo.s0[o] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
             qo.s1[o] = make_float4(att.x, att.y, att.z, __uint_as_float(k1));
         }
+        const bool wave_finite = __all(!shadow || (isfinite(hp.x) && isfinite(hp.y) && isfinite(hp.z)));
         if (shadow) {
             // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
             const long long o = seg_base_o + sh_base[1] + off_s;
@@ -899,10 +900,16 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             const v3 ab = vmul(att, beta);
             // one light (the common case): its index is wave-uniform, so its instance/primitive records are scalar
             // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
-            auto light_sample = [&](const uint32_t k, const uint32_t kb, const int light) {
-                const v3 ldir = instance_random(S, light, hp, k0, k1, kb + 1);
+            // tr: the light's transform is a pure translation and every hit point of this wave is finite (same exactness
+            // argument as in world_hit_n): local point = translation + p, directions are unchanged
+            auto light_sample = [&](const uint32_t k, const uint32_t kb, const int light, const bool tr) {
+                const DInst &lin = S.insts[light];
+                const DPrim &lpr = S.prims[lin.prim];
+                const v3 ol = tr ? V(lin.inv[3] + hp.x, lin.inv[7] + hp.y, lin.inv[11] + hp.z) : xf_point(lin.inv, hp);
+                const v3 dl = prim_random(lpr, ol, k0, k1, kb + 1);                       // instance::random primitive.h:338-342
+                const v3 ldir = tr ? dl : xf_linear(lin.fwd, dl);
                 const float cos_l = vdot(vunit(ldir), vunit(hn));
-                const float light_pdf_l = instance_pdf_value(S, light, hp, ldir);
+                const float light_pdf_l = prim_pdf_value(lpr, ol, tr ? ldir : xf_linear(lin.inv, ldir));   // primitive.h:319-337
                 const float scatter_pdf_l = material_value(mat_type, hn, ldir);
                 const float weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
                 const float dropoff = cos_l > 0.0f ? cos_l : 0.0f;
@@ -916,12 +923,13 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             };
             if (S.n_lights == 1) {
                 const int light = S.lights[0];
-                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), light);
+                const bool tr = S.insts[light].ident && wave_finite;
+                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), light, tr);
             } else {
                 for (uint32_t k = 0; k < L; k++) {
                     const uint32_t kb = base + NV + k * (3u + NV);
                     const int idx = (int)(rnd(k0, k1, kb + 0) * (double)S.n_lights);   // world.h:31-35
-                    light_sample(k, kb, S.lights[idx]);
+                    light_sample(k, kb, S.lights[idx], false);
                 }
             }
         }
