@@ -66,12 +66,20 @@ def main():
 
     if not torch.cuda.is_available() or pt.device_count() < 1:
         sys.exit("bench.py: no MI355X visible -- the hot path has no CPU fallback")
+    # PT_BENCH_REHEARSAL=1: every rank on GPU 0, gloo instead of RCCL, the reduce staged through host memory.  Only for
+    # exercising the N > 1 code path on a one-GPU box; its numbers mean nothing.
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if n > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=n)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
 
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
     r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * SPP_PER_STEP)
@@ -103,15 +111,21 @@ def main():
     for i in range(args.steps):
         step(i)
     r.wait()
-    reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
+    if rehearsal and dist is not None:
+        fb_host = fb.cpu()
+        reduce_framebuffer(fb_host, dst=0)
+        fb.copy_(fb_host)
+    else:
+        reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
     sync()
     dt = time.perf_counter() - t0
 
     ctr = r.counters()
     kt = r.kernel_times()
+    red_dev = "cpu" if rehearsal else f"cuda:{local_rank}"
     rays = torch.tensor([ctr["rays"], ctr["camera_samples"], ctr["extension_rays"], ctr["extension_hits"],
-                         ctr["shadow_rays"]], dtype=torch.float64, device=f"cuda:{local_rank}")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+                         ctr["shadow_rays"]], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -183,6 +197,10 @@ def main():
                    "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays), oracle stream mode, "
                              f"{cores} threads, {cdt:.2f} s wall"}
 
+        if rehearsal:
+            img = fb.cpu().numpy()[..., :3]
+            print(json.dumps({"rehearsal_fb_sum": float(img.astype("float64").sum()), "spp_total": spp_step * args.steps,
+                              "nonzero_pixels": int((img.sum(axis=2) != 0).sum())}), file=sys.stderr, flush=True)
         out = {
             "metric": "Mrays/sec + achieved HBM GB/s %peak, cornell_box 1080p@1024spp, 1/2/4/8 GPU",
             "value": round(total_rays / dt / 1e6, 2),
