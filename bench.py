@@ -9,9 +9,10 @@ roulette on, normal_offset 1e-4.  One *step* = one wavefront pass over the whole
 per pixel (one batch of ~33 M camera samples per GPU); the default K = 64 steps at N = 1 is exactly the 1024 spp of
 configs[1].  "ray" = one World::hit query, extension + shadow, the reference's own unit (integrator.h:192,247).
 
-N > 1: one process per GPU; the image is partitioned by 128x128 tile in NaiveSpiral order, tile k -> rank k mod N
-(SURVEY.md 8e), every rank renders its tiles with no communication, and ONE RCCL sum-reduce of the framebuffer to
-rank 0 ends the timed region.  Per-GPU work is held fixed as N grows (samples per step scale with N): "weak".
+N > 1: one process per GPU; the image is partitioned by 128x128 tile in NaiveSpiral order, ownership
+balanced over measured per-tile ray counts (pathtrace_amd/distributed.py; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank
+k mod N), every rank renders its tiles with no communication, and ONE RCCL sum-reduce of the framebuffer to rank 0
+ends the timed region.  Per-GPU work is held fixed as N grows (samples per step scale with N): "weak".
 
 The timed region holds only GPU work on device-resident data (scene tables + streams live in HBM; there are no host
 buffers on the path).  Rank 0 also reports:
@@ -88,8 +89,16 @@ def main():
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
     spp_step = SPP_PER_STEP * n
-    from pathtrace_amd.distributed import reduce_framebuffer, tiles_for_rank
-    my_tiles = [(0, 0, WIDTH, HEIGHT)] if n == 1 else tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n)
+    from pathtrace_amd.distributed import measure_tile_costs, reduce_framebuffer, tiles_for_rank
+    if n == 1:
+        my_tiles = [(0, 0, WIDTH, HEIGHT)]
+    else:
+        # scheduling set-up, like the scene upload outside the timed region: every rank counts the rays of one sample
+        # per pixel per tile (identical integers on every rank) and derives the same cost-balanced ownership map
+        costs = None
+        if os.environ.get("PT_BENCH_ROUND_ROBIN") != "1":
+            costs = measure_tile_costs(r, pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE))
+        my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
 
     def step(i):
         r.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
@@ -214,7 +223,7 @@ def main():
                        "spp_total": spp_step * args.steps, "camera_samples": int(total_samples), "rays": int(total_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
-                       "partition": "whole frame" if n == 1 else f"128x128 tiles, spiral order, tile k -> rank k mod {n}; 1 RCCL reduce"},
+                       "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce")},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

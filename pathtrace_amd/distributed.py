@@ -4,20 +4,68 @@ The path shards by image tile -- `block_width x block_height` tiles in the refer
 (queue.h:68-127), tile k owned by rank k mod world -- with no communication while rendering; the single exchange is a
 sum-reduce of the RGBA framebuffer onto rank 0 (RCCL over xGMI when the backend is "nccl").  Because tile ownership is
 disjoint, every pixel receives exactly one non-zero contribution, so the reduced image is bit-identical to a
-single-GPU render for any world size.  No rendering happens in this module.
+single-GPU render for any world size and any ownership map.  No rendering happens in this module.
+
+k mod world balances pixels but not work: the spiral's rings beat against the world size and the Cornell box's interior
+tiles cost ~10x the background ones (rays per rank 6 % / 7.5 % above the mean at 4 / 8 ranks at 1080p).  When per-tile
+costs are known (`measure_tile_costs`: one sample per pixel, counted in the reference's own unit, World::hit queries,
+integrator.h:192,247) ownership is the longest-processing-time greedy over them instead: every rank measures the same
+integers, so every rank derives the same map without talking to the others.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 from . import spiral_tiles
 
 
-def tiles_for_rank(width: int, height: int, block_w: int, block_h: int, rank: int, world: int) -> List[Tuple[int, int, int, int]]:
-    """Tile rects (x0, y0, x1, y1) owned by `rank`: NaiveSpiral order, round-robin (balances the cheap border tiles)."""
+def balanced_owners(costs: Sequence[int], world: int) -> List[int]:
+    """Owner rank of every tile: longest-processing-time greedy (costliest tile first, ties by spiral index, to the least
+    loaded rank, ties to the lowest rank).  Pure integer arithmetic: identical on every rank for identical costs."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    costs = [int(c) for c in costs]
+    if any(c < 0 for c in costs):
+        raise ValueError("tile costs must be non-negative")
+    load = [0] * world
+    owner = [0] * len(costs)
+    for k in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k] = r
+        load[r] += costs[k]
+    return owner
+
+
+def tiles_for_rank(width: int, height: int, block_w: int, block_h: int, rank: int, world: int,
+                   costs: Optional[Sequence[int]] = None) -> List[Tuple[int, int, int, int]]:
+    """Tile rects (x0, y0, x1, y1) owned by `rank`, in NaiveSpiral order.  Without costs: tile k -> rank k mod world;
+    with one cost per spiral tile: the cost-balanced map of `balanced_owners`."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world of {world}")
-    return spiral_tiles(width, height, block_w, block_h)[rank::world]
+    tiles = spiral_tiles(width, height, block_w, block_h)
+    if costs is None:
+        return tiles[rank::world]
+    if len(costs) != len(tiles):
+        raise ValueError(f"{len(costs)} costs for {len(tiles)} tiles")
+    owner = balanced_owners(costs, world)
+    return [t for t, o in zip(tiles, owner) if o == rank]
+
+
+def measure_tile_costs(renderer, tiles) -> List[int]:
+    """Work per tile in ray-equivalents: World::hit queries of one sample per pixel plus one unit per camera sample (ray
+    generation + framebuffer accumulation).  `renderer` is a pathtrace_amd.Renderer; its framebuffer and counters are
+    cleared afterwards.  Deterministic (the RNG is keyed by pixel and sample), so all ranks agree."""
+    costs = []
+    renderer.clear()
+    prev = renderer.counters()
+    for t in tiles:
+        renderer.render_tiles_async([t], 0, 1)
+        renderer.wait()
+        c = renderer.counters()
+        costs.append((c["rays"] - prev["rays"]) + (c["camera_samples"] - prev["camera_samples"]))
+        prev = c
+    renderer.clear()
+    return costs
 
 
 def reduce_framebuffer(fb, dst: int = 0):

@@ -22,19 +22,27 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, balanced):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import pt_oracle
+    from pathtrace_amd import spiral_tiles
     from pathtrace_amd.distributed import reduce_framebuffer, tiles_for_rank
 
     osc = pt_oracle.Scene.from_json(scene_path("cornell_box"))
     cfg = pt_oracle.make_config(W, H, SPP)
     fb3 = np.zeros((H, W, 3), np.float32)
-    mine = tiles_for_rank(W, H, TILE, TILE, rank, world)
+    costs = None
+    if balanced:   # per-tile ray counts of one sample per pixel, measured by every rank on its own (identical integers)
+        costs = []
+        scratch = np.zeros((H, W, 3), np.float32)
+        for rect in spiral_tiles(W, H, TILE, TILE):
+            _, c = osc.render_stream(cfg, seed=0, rect=rect, s0=0, s1=1, threads=2, fb=scratch)
+            costs.append(c["rays"] + (rect[2] - rect[0]) * (rect[3] - rect[1]))
+    mine = tiles_for_rank(W, H, TILE, TILE, rank, world, costs)
     for (x0, y0, x1, y1) in mine:
         osc.render_stream(cfg, seed=0, rect=(x0, y0, x1, y1), threads=2, fb=fb3)
     fb = torch.zeros((H, W, 4), dtype=torch.float32)
@@ -49,9 +57,10 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_tile_partition_and_reduce_world2(tmp_path, oracle):
+@pytest.mark.parametrize("balanced", [False, True], ids=["round_robin", "cost_balanced"])
+def test_tile_partition_and_reduce_world2(tmp_path, oracle, balanced):
     out = str(tmp_path / "fb.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, balanced), nprocs=2, join=True)
     got = np.load(out)
     ref, _ = oracle.Scene.from_json(scene_path("cornell_box")).render_stream(oracle.make_config(W, H, SPP), seed=0, threads=2)
     assert np.array_equal(got[..., :3].view(np.uint32), ref.view(np.uint32))
@@ -72,3 +81,38 @@ def test_tile_ownership_is_a_partition():
         assert (cover == 1).all() and max(n) - min(n) <= 1
     with pytest.raises(ValueError):
         tiles_for_rank(64, 64, 32, 32, 2, 2)
+
+
+def test_cost_balanced_ownership():
+    from pathtrace_amd import spiral_tiles
+    from pathtrace_amd.distributed import balanced_owners, tiles_for_rank
+
+    rng = np.random.default_rng(7)
+    for (w, h, world) in [(1920, 1080, 8), (1920, 1080, 4), (3840, 2160, 8), (200, 200, 2), (96, 54, 3)]:
+        tiles = spiral_tiles(w, h, 128, 128)
+        # a cost field shaped like the Cornell box: expensive centre, cheap border
+        cx = np.array([(t[0] + t[2]) / 2 / w - 0.5 for t in tiles])
+        cy = np.array([(t[1] + t[3]) / 2 / h - 0.5 for t in tiles])
+        costs = (1000 + 9000 * np.exp(-8 * (cx * cx + cy * cy)) + rng.integers(0, 50, len(tiles))).astype(np.int64).tolist()
+        owner = balanced_owners(costs, world)
+        assert owner == balanced_owners(list(costs), world)            # deterministic
+        cover = np.zeros((h, w), np.int32)
+        got = []
+        for r in range(world):
+            t = tiles_for_rank(w, h, 128, 128, r, world, costs)
+            assert t == [tiles[k] for k in range(len(tiles)) if owner[k] == r]   # spiral order kept
+            got += t
+            for x0, y0, x1, y1 in t:
+                cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all() and sorted(got) == sorted(tiles)
+        load = lambda own: max(sum(c for c, o in zip(costs, own) if o == r) for r in range(world))
+        rr = [k % world for k in range(len(tiles))]
+        assert load(owner) <= load(rr)
+        if len(tiles) >= 8 * world:
+            assert load(owner) <= 1.02 * sum(costs) / world
+    assert balanced_owners([], 3) == [] and balanced_owners([5, 5, 5], 1) == [0, 0, 0]
+    assert balanced_owners([3, 3, 3, 3], 2) == [0, 1, 0, 1]               # ties: spiral index, then lowest rank
+    with pytest.raises(ValueError):
+        tiles_for_rank(256, 256, 128, 128, 0, 2, costs=[1, 2, 3])
+    with pytest.raises(ValueError):
+        balanced_owners([1, -1], 2)

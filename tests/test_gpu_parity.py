@@ -132,6 +132,35 @@ def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
     r.close()
 
 
+def test_cost_balanced_tile_ownership(oracle):
+    # the N > 1 scheduler on one GPU: per-tile costs measured through the C ABI equal the oracle's ray counts, the
+    # ownership map derived from them is a partition, and the "ranks" rendered back to back give the one-GPU image
+    from pathtrace_amd.distributed import measure_tile_costs, tiles_for_rank
+
+    scene, w, h, spp, tile, world = "cornell_box", 320, 180, 4, 64, 3
+    whole, c0 = gpu_render(scene, w, h, spp)
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc)
+    tiles = pt.spiral_tiles(w, h, tile, tile)
+    costs = measure_tile_costs(r, tiles)
+    osc = oracle.Scene.from_json(scene_path(scene))
+    cfg = oracle_cfg(oracle, w, h, 1)
+    scratch = np.zeros((h, w, 3), np.float32)
+    for k in (0, 1, len(tiles) // 2, len(tiles) - 1):
+        _, oc = osc.render_stream(cfg, seed=0, rect=tiles[k], threads=2, fb=scratch)
+        assert costs[k] == oc["rays"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1])
+    assert r.counters()["rays"] == 0 and not r.framebuffer().any()      # measuring leaves no trace
+    per_rank = [tiles_for_rank(w, h, tile, tile, k, world, costs) for k in range(world)]
+    assert sorted(t for tr in per_rank for t in tr) == sorted(tiles)
+    loads = [sum(costs[tiles.index(t)] for t in tr) for tr in per_rank]
+    rr = [sum(costs[k::world]) for k in range(world)]
+    assert max(loads) <= max(rr)
+    for tr in per_rank:
+        r.render_tiles_async(tr, 0, spp)
+    assert np.array_equal(bits(whole), bits(r.framebuffer())) and r.counters() == c0
+    r.close()
+
+
 def test_seed_changes_the_stream_but_not_the_estimate(oracle):
     scene, w, h, spp = "cornell_box", 64, 64, 64
     a, _ = gpu_render(scene, w, h, spp, seed=1)
