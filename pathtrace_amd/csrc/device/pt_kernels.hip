@@ -961,7 +961,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
 template <int NR>
-__global__ __launch_bounds__(PT_BLOCK) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
