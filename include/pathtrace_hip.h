@@ -137,6 +137,11 @@ int pt_wait(pt_ctx *ctx);
 /* Copy the linear float framebuffer SUM (not mean; renderer.h:682) to host: height*width*3 floats,
  * row 0 = bottom row, i.e. framebuffer[j][i] of renderer.h:141.  Waits for pending work. */
 int pt_read_framebuffer(pt_ctx *ctx, float *rgb_sum);
+/* Progressive preview (Tiled::sync_progress renderer.h:605-620 re-writes the PPM from the LIVE framebuffer with the
+ * divisor 1 + samples_done / (W*H)): copy the framebuffer SUM as it stands, without waiting for the work that is
+ * still queued.  *samples_accumulated = camera samples of the batches known to be fully accumulated when the copy
+ * started (a lower bound of what the copy holds; exact once the context is idle).  Same layout as above. */
+int pt_snapshot_framebuffer(pt_ctx *ctx, float *rgb_sum, uint64_t *samples_accumulated);
 int pt_clear_framebuffer(pt_ctx *ctx);
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);   /* totals since pt_create / pt_clear_framebuffer; waits */
 

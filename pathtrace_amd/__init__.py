@@ -88,7 +88,7 @@ class HostConfig(C.Structure):
 
 
 # every symbol include/pathtrace_hip.h declares
-EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer",
+EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
@@ -117,6 +117,7 @@ def lib():
     L.pt_poll.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pt_wait.argtypes = [vp]
     L.pt_read_framebuffer.argtypes = [vp, fp]
+    L.pt_snapshot_framebuffer.argtypes = [vp, fp, C.POINTER(C.c_uint64)]
     L.pt_clear_framebuffer.argtypes = [vp]
     L.pt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.pt_device_framebuffer.argtypes = [vp]
@@ -273,6 +274,13 @@ class Renderer:
         fb = np.zeros((self.height, self.width, 3), np.float32)
         _check(lib().pt_read_framebuffer(self._h, fb.ctypes.data_as(C.POINTER(C.c_float))), "pt_read_framebuffer")
         return fb
+
+    def snapshot(self):
+        """(framebuffer SUM as it stands, camera samples known to be accumulated) without waiting for queued work."""
+        fb = np.zeros((self.height, self.width, 3), np.float32)
+        n = C.c_uint64()
+        _check(lib().pt_snapshot_framebuffer(self._h, fb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)), "pt_snapshot_framebuffer")
+        return fb, n.value
 
     def clear(self):
         _check(lib().pt_clear_framebuffer(self._h), "pt_clear_framebuffer")

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../../include/pathtrace_hip.h"
@@ -87,6 +88,13 @@ struct pt_ctx {
     float4 *fb_own = nullptr;
     DCounters *host_ctr = nullptr;   // pinned mirror of all banks, refreshed after every batch
     DCounters host_sum{};            // banks summed (by sum_counters)
+    // progressive preview (pt_snapshot_framebuffer): one event per batch after its k_accumulate, in enqueue order
+    struct Mark { hipEvent_t ev; uint64_t cum_samples; };
+    std::deque<Mark> marks;
+    std::vector<hipEvent_t> mark_free;
+    uint64_t enqueued_samples = 0, accumulated_samples = 0;
+    hipStream_t snap_stream = nullptr;
+    float4 *snap_host = nullptr;     // pinned staging for the live-framebuffer copy
     DBatch last_batch{};
     bool have_last = false;
     // tile table of the current / last pt_render_tiles_async call (device copy + host mirror for reuse)
@@ -418,6 +426,10 @@ extern "C" void pt_destroy(pt_ctx *c)
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->host_ctr) (void)hipHostFree(c->host_ctr);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto &m : c->marks) (void)hipEventDestroy(m.ev);
+    for (auto e : c->mark_free) (void)hipEventDestroy(e);
+    if (c->snap_host) (void)hipHostFree(c->snap_host);
+    if (c->snap_stream) (void)hipStreamDestroy(c->snap_stream);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -435,6 +447,16 @@ static const DCounters &sum_counters(pt_ctx *c)
     }
     c->host_sum = s;
     return c->host_sum;
+}
+
+// batches accumulate in enqueue order (run_batch chains the k_accumulate launches), so the finished ones are a prefix
+static void retire_marks(pt_ctx *c)
+{
+    while (!c->marks.empty() && hipEventQuery(c->marks.front().ev) == hipSuccess) {
+        c->accumulated_samples = c->marks.front().cum_samples;
+        c->mark_free.push_back(c->marks.front().ev);
+        c->marks.pop_front();
+    }
 }
 
 static hipEvent_t get_event(pt_ctx *c, size_t i)
@@ -495,6 +517,15 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->host_ctr, st.counters, sizeof(DCounters) * PT_COUNTER_BANKS, hipMemcpyDeviceToHost, sm));
     HIP_TRY(hipEventRecord(ln.acc_done, sm));
+    {   // batch mark for pt_snapshot_framebuffer; finished marks are retired here so the list stays short
+        retire_marks(c);
+        hipEvent_t ev = nullptr;
+        if (!c->mark_free.empty()) { ev = c->mark_free.back(); c->mark_free.pop_back(); }
+        else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev, sm));
+        c->enqueued_samples += (uint64_t)b.n_paths;
+        c->marks.push_back({ev, c->enqueued_samples});
+    }
     c->last_lane = li;
     c->last_batch = b;
     c->last_batch_lane = li;
@@ -669,6 +700,32 @@ extern "C" int pt_clear_framebuffer(pt_ctx *c)
     c->last_lane = -1;
     memset(c->host_ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS);
     c->ctr_at_profile_start = DCounters{};
+    retire_marks(c);
+    c->enqueued_samples = c->accumulated_samples = 0;
+    return 0;
+}
+
+// Progressive preview: the reference's sync_progress (renderer.h:605-620) reads the framebuffer while its worker
+// threads are still adding to it.  Here a copy engine reads the live framebuffer on a stream of its own while the
+// render streams keep running; `samples_accumulated` is taken BEFORE the copy starts, so every pixel holds at least
+// the batches counted (a pixel may already include the next batch -- the same looseness as the reference's).
+extern "C" int pt_snapshot_framebuffer(pt_ctx *c, float *rgb_sum, uint64_t *samples_accumulated)
+{
+    if (!c || !rgb_sum) { set_err("pt_snapshot_framebuffer: null argument"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->cfg.width * c->cfg.height;
+    if (!c->snap_stream) HIP_TRY(hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+    if (!c->snap_host) HIP_TRY(hipHostMalloc((void **)&c->snap_host, n * sizeof(float4)));
+    retire_marks(c);
+    const uint64_t done = c->accumulated_samples;
+    HIP_TRY(hipMemcpyAsync(c->snap_host, c->st.fb, n * sizeof(float4), hipMemcpyDeviceToHost, c->snap_stream));
+    HIP_TRY(hipStreamSynchronize(c->snap_stream));
+    for (size_t i = 0; i < n; i++) {
+        rgb_sum[3 * i + 0] = c->snap_host[i].x;
+        rgb_sum[3 * i + 1] = c->snap_host[i].y;
+        rgb_sum[3 * i + 2] = c->snap_host[i].z;
+    }
+    if (samples_accumulated) *samples_accumulated = done;
     return 0;
 }
 

@@ -700,6 +700,17 @@ public:
         double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - render_start).count();
         printf("samples left %20ld rate %10.0f\r", total - (long)samples, dt > 0 ? samples / dt : 0.0);
         fflush(stdout);
+        // preview PPM from the live framebuffer, divisor 1 + done / (W*H) (renderer.h:617-618); like the reference's
+        // main loop (one sync_progress per 0.5 s, main.cpp:158-163) at most two previews per second
+        if (r == 0 && dt - last_preview >= 0.5) {
+            uint64_t acc = 0;
+            if (pt_snapshot_framebuffer(ctx, framebuffer.data(), &acc)) throw JsonError(pt_last_error());
+            const long npix = (long)config.width * config.height;
+            if (pth_write_ppm(config.ppm_output_path, framebuffer.data(), config.width, config.height, (int32_t)(1 + (long)acc / npix), config.exposure))
+                throw JsonError(pt_last_error());
+            last_preview = dt;
+            previews++;
+        }
         completed = r == 1;
     }
     bool is_done() override { return completed; }
@@ -718,6 +729,8 @@ public:
     }
     pt_ctx *ctx = nullptr;
     std::chrono::high_resolution_clock::time_point render_start;
+    double last_preview = 0.0;
+    int previews = 0;
 };
 
 }  // namespace pth

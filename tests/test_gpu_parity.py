@@ -161,6 +161,49 @@ def test_cost_balanced_tile_ownership(oracle):
     r.close()
 
 
+def test_progressive_snapshot_of_the_live_framebuffer(tmp_path):
+    # SURVEY 8f-3 (renderer.h:605-620): the preview reads the framebuffer while the render is still running.  A snapshot
+    # must not wait for the queued work, its sample count is monotone, every pixel is a prefix sum of that pixel's
+    # samples (radiance >= 0, so prefix sums are bounded by the final sum) holding AT LEAST the counted batches, and once
+    # idle it is the framebuffer.
+    scene, w, h, spp = "cornell_box", 480, 270, 64
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, max_paths_in_flight=w * h * 2)          # 32 batches of 2 spp
+    prefix = {}
+    for k in (2, 4, 8, 16, 32, 64):
+        r.clear()
+        r.render_async(0, k)
+        prefix[k] = r.framebuffer()
+    final = prefix[spp]
+    r.clear()
+    r.render_async(0, spp)
+    seen, busy_snaps = [], 0
+    while True:
+        done, _, _ = r.poll()
+        fb, n = r.snapshot()
+        seen.append(n)
+        assert n % (w * h * 2) == 0 and n <= w * h * spp
+        assert (fb <= final).all() and (fb >= 0).all()
+        k = n // (w * h)
+        if k in prefix:
+            assert (fb >= prefix[k]).all()
+        if not done:
+            busy_snaps += 1
+        if done:
+            break
+    assert seen == sorted(seen)
+    fb, n = r.snapshot()
+    assert n == w * h * spp and np.array_equal(bits(fb), bits(final)) and np.array_equal(bits(fb), bits(r.framebuffer()))
+    assert busy_snaps >= 1, "the render finished before the first snapshot: enlarge the job"
+    # the preview file the plugin writes from such a snapshot: divisor 1 + done / (W*H)
+    out = str(tmp_path / "preview.ppm")
+    pt.write_ppm(out, prefix[8], 1 + 8)
+    assert open(out, "rb").read().startswith(b"P6\n480 270\n255\n")
+    r.clear()
+    assert r.snapshot()[1] == 0 and not r.snapshot()[0].any()
+    r.close()
+
+
 def test_seed_changes_the_stream_but_not_the_estimate(oracle):
     scene, w, h, spp = "cornell_box", 64, 64, 64
     a, _ = gpu_render(scene, w, h, spp, seed=1)
