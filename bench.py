@@ -192,19 +192,46 @@ def main():
                     "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)}
 
         cpu = None
+        parity = None
         if not args.no_cpu_baseline:
             from oracle import pt_oracle
             avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             cores = min(avail, 16)   # one GPU's share of the host (the GPU box guideline), all of them used
             osc = pt_oracle.Scene.from_json(args.scene)
-            spp_cpu = 4
+            spp_cpu = 64   # ~1.1e9 rays: 10-15 s on 16 host threads
             cfg = pt_oracle.make_config(WIDTH, HEIGHT, spp_cpu)
             c0 = time.perf_counter()
-            _, octr = osc.render_stream(cfg, seed=0, threads=cores)
+            ofb, octr = osc.render_stream(cfg, seed=0, threads=cores)
             cdt = time.perf_counter() - c0
+            # the reference's own order on one thread (global mt19937, config 1 = 200x200x16): ties the port back to the
+            # reference's single-thread rate; the literal reference binary cannot travel to this box
+            mcfg = pt_oracle.make_config(200, 200, 16)
+            osc_mt = pt_oracle.Scene.from_json(args.scene)
+            m0 = time.perf_counter()
+            _, mctr = osc_mt.render_mt(mcfg)
+            mdt = time.perf_counter() - m0
             cpu = {"value": round(octr["rays"] / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays), oracle stream mode, "
-                             f"{cores} threads, {cdt:.2f} s wall"}
+                             f"{cores} threads, {cdt:.2f} s wall",
+                   "reference_order_1thread": {"value": round(mctr["rays"] / mdt / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                                               "sample": f"cornell_box 200x200x16 ({mctr['rays']} rays), oracle mt19937 mode, "
+                                                         f"{mdt:.2f} s wall"}}
+            if n == 1:
+                # parity reported with the metric, at the bench's full frame size: the same 4 spp on the
+                # GPU must be the oracle's framebuffer bit for bit, with equal path counters
+                import numpy as np
+                r.clear()
+                r.render_async(0, spp_cpu)
+                gfb = r.framebuffer()
+                gctr = r.counters()
+                same = (gfb.view(np.uint32) == ofb.view(np.uint32)) | (gfb == ofb)
+                parity = {"against": "oracle stream mode, same seed", "size": f"{WIDTH}x{HEIGHT}x{spp_cpu}",
+                          "pixel_channels": int(same.size), "mismatched": int((~same).sum()), "tolerance_ulp": 0,
+                          "counters_equal": all(gctr[g] == octr[o] for g, o in (
+                              ("rays", "rays"), ("extension_rays", "ext_rays"), ("extension_hits", "ext_hits"),
+                              ("shadow_rays", "shadow_rays"), ("term_miss", "term_miss"), ("term_rr", "term_rr"),
+                              ("term_emitter", "term_emitter"), ("term_pdf", "term_pdf"),
+                              ("term_bounce_limit", "term_bounce_limit")))}
 
         if rehearsal:
             img = fb.cpu().numpy()[..., :3]
@@ -226,6 +253,7 @@ def main():
                        "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "parity": parity,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerates the measurement evidence under profiles/ on a GPU box (run through gpurun from the repo root):
+#   tools/profile_gpu.sh r01d
+#   1. default bench.py line                                   -> gpurun_out/<tag>_bench_default.json
+#   2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/<tag>_kernel_stats.csv
+#   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)      -> gpurun_out/<tag>_pmc_{fetch,write}.csv
+# tools/summarize_profiles.py then writes profiles/<tag>_* and profiles/hbm_traffic.json from these (it runs here too,
+# so the merged gpurun_out/ already holds the summaries; copy them into profiles/ and commit).
+set -o pipefail
+TAG=${1:-r01x}
+R=$(pwd)
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+timeout -k 10 500 python3 "$R/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench.err" || { echo "bench failed"; tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
+cd /tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -- python3 "$R/bench.py" --no-cpu-baseline > "$OUT/${TAG}_prof.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/${TAG}_prof.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/${TAG}_pmc_fetch.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmc_write" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/${TAG}_pmc_write.log"; exit 1; }
+cd "$R"
+python3 tools/summarize_profiles.py "$TAG" "$OUT"

@@ -1,0 +1,78 @@
+"""Condense the rocprofv3 output of tools/profile_gpu.sh into the small files kept under profiles/.
+
+    python tools/summarize_profiles.py <tag> <dir with <tag>_prof/, <tag>_pmc_fetch/, <tag>_pmc_write/>
+
+Writes (into <dir>/summary_<tag>/, to be copied to profiles/):
+  <tag>_kernel_stats.csv   rocprofv3's own kernel_stats table (name, calls, total/avg/min/max ns, %)
+  hbm_traffic.json         per kernel: FETCH_SIZE / WRITE_SIZE (KB, summed over XCDs) per launch and
+                           hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: the gfx950 correction of
+                           /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3) -- wide coalesced reads are
+                           under-reported by 2x, writes are not.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+KERNELS = ("generate", "extend", "shade", "connect", "accumulate")
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+def kname(full):
+    for k in KERNELS:
+        if "k_" + k in full:
+            return k
+    return None
+
+
+def pmc_per_launch(d, counter):
+    f = find(d, "counter_collection.csv")
+    if not f:
+        return {}
+    per = defaultdict(lambda: defaultdict(float))   # kernel -> dispatch id -> value
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if row.get("Counter_Name") != counter:
+                continue
+            k = kname(row.get("Kernel_Name", ""))
+            if k:
+                per[k][row.get("Dispatch_Id")] += float(row.get("Counter_Value", 0))
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items() if v}
+
+
+def main():
+    tag, d = sys.argv[1], sys.argv[2]
+    out = os.path.join(d, "summary_" + tag)
+    os.makedirs(out, exist_ok=True)
+    ks = find(os.path.join(d, tag + "_prof"), "kernel_stats.csv")
+    if ks:
+        shutil.copy(ks, os.path.join(out, tag + "_kernel_stats.csv"))
+    b = os.path.join(d, tag + "_bench_default.json")
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(out, tag + "_bench_default.json"))
+    fetch = pmc_per_launch(os.path.join(d, tag + "_pmc_fetch"), "FETCH_SIZE")
+    write = pmc_per_launch(os.path.join(d, tag + "_pmc_write"), "WRITE_SIZE")
+    res = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_gpu.sh " + tag + "), "
+                   "bench.py --steps 4 --warmup 1 (16 spp batches, 1080p); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                   "the gfx950 correction for wide coalesced reads; averages over all launches of all bounces"}
+    for k in KERNELS:
+        if k in fetch and k in write:
+            fk, n = fetch[k]
+            wk, _ = write[k]
+            res[k] = {"launches_sampled": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
+                      "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != "note"}))
+    if ks:
+        print(open(ks).read()[:1500])
+
+
+if __name__ == "__main__":
+    main()
