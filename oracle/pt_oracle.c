@@ -138,6 +138,56 @@ void ptm_sincos_2pi(float r, float *s, float *c)
     *s = ss;
     *c = cc;
 }
+/* sinf for checker_texture::sines (texture.h:70-73).  Double arithmetic throughout (+,-,*, rint; no contraction), so the
+ * CPU and the GPU agree bit for bit; the float result is within 1 ulp of libm's for |x| < 1e6 (three-term Cody-Waite
+ * reduction whose first two products are exact for |k| < 2^20), the same formula with slowly degrading accuracy up to
+ * 2^30, and x - x (NaN for inf / NaN, 0 otherwise) beyond. */
+static double ptm_sin_reduced(double r, int q)
+{
+    const double r2 = r * r;
+    const double sp = r + r * r2 * (-1.6666666666666666e-01 + r2 * (8.3333333333333332e-03 + r2 * (-1.9841269841269841e-04
+                      + r2 * (2.7557319223985893e-06 + r2 * (-2.5052108385441720e-08 + r2 * 1.6059043836821613e-10)))));
+    const double cp = 1.0 + r2 * (-0.5 + r2 * (4.1666666666666664e-02 + r2 * (-1.3888888888888889e-03 + r2 * (2.4801587301587302e-05
+                      + r2 * (-2.7557319223985888e-07 + r2 * (2.0876756987868100e-09 + r2 * -1.1470745597729725e-11))))));
+    return (q & 1) ? ((q & 2) ? -cp : cp) : ((q & 2) ? -sp : sp);
+}
+float ptm_sinf(float x)
+{
+    if (!(fabsf(x) < 1073741824.0f)) return x - x;
+    const double xd = (double)x;
+    const double k = rint(xd * 0.63661977236758138);
+    /* pi/2 = C1 + C2 + C3, C1 and C2 with 33 significant bits */
+    const double r = ((xd - k * 1.5707963267341256) - k * 6.077100506303966e-11) - k * 2.0222662487959506e-21;
+    return (float)ptm_sin_reduced(r, (int)k & 3);
+}
+/* atan2f / acosf for the environment-map coordinates of a missed ray (integrator.h:327-330); same rules as ptm_sinf */
+static double ptm_atan2_d(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    double a = (mx > 0.0) ? mn / mx : 0.0;            /* [0, 1] */
+    double off = 0.0;
+    if (a > 0.41421356237309503) { a = (a - 1.0) / (a + 1.0); off = 0.78539816339744828; }   /* atan a = pi/4 + atan((a-1)/(a+1)) */
+    const double z = a * a;
+    double p = 1.0 / 27.0;
+    p = 1.0 / 25.0 - z * p; p = 1.0 / 23.0 - z * p; p = 1.0 / 21.0 - z * p; p = 1.0 / 19.0 - z * p; p = 1.0 / 17.0 - z * p;
+    p = 1.0 / 15.0 - z * p; p = 1.0 / 13.0 - z * p; p = 1.0 / 11.0 - z * p; p = 1.0 / 9.0 - z * p; p = 1.0 / 7.0 - z * p;
+    p = 1.0 / 5.0 - z * p; p = 1.0 / 3.0 - z * p; p = 1.0 - z * p;
+    double t = off + a * p;                          /* atan(mn / mx) in [0, pi/4] */
+    if (ay > ax) t = 1.5707963267948966 - t;
+    if (x < 0.0) t = 3.1415926535897931 - t;
+    return (y < 0.0) ? -t : t;
+}
+float ptm_atan2f(float y, float x)
+{
+    if (x != x || y != y) return x + y;
+    return (float)ptm_atan2_d((double)y, (double)x);
+}
+float ptm_acosf(float x)
+{
+    const double xd = (double)x;
+    return (float)ptm_atan2_d(sqrt((1.0 - xd) * (1.0 + xd)), xd);   /* NaN outside [-1, 1], like libm */
+}
 /* cube root for x in [0, 1]: bit-trick seed + 3 Newton steps (float +,-,*,/ only) */
 float ptm_cbrtf(float x)
 {
@@ -179,7 +229,18 @@ typedef struct {
     v3 color;
     float alpha, power;
     int two_sided;
+    int tex; /* texture index when albedo / emit is not a constant texture, else -1 */
 } mat_t;
+
+typedef struct {
+    int type;
+    v3 color;
+    float alpha;
+    int even, odd;
+    float scale;
+    int width, height;
+    const uint8_t *rgba; /* image: into pto_scene.texels */
+} tex_t;
 
 typedef struct { float x0, z0, x1, z1, y; int plane; int normal; /* = !flipped */ int mat; } rect_t;
 
@@ -212,6 +273,12 @@ struct pto_scene {
     int *lights;
     pto_camera cam;
     v3 background;
+    int background_tex; /* World::background when it is not a constant texture, else -1 */
+    int ntex;
+    tex_t *tex;
+    uint8_t *texels;
+    v3 ranvec[256];      /* perlin::ranvec, perm_x/y/z (texture.h:176-183), from the static-init draws */
+    int perm[3][256];
     mt19937 rng; /* the process-wide generator of random.h:12 */
 };
 
@@ -687,11 +754,39 @@ static rect_t make_rect(float x0, float z0, float x1, float z1, float y, int mat
     return r;
 }
 
+static void perlin_static_init(mt19937 *g, v3 ranvec[256], int perm[3][256]);
 pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *prims, int nprim,
                             const pto_instance *insts, int ninst, const pto_camera *cam, const float background[3])
 {
-    if (ninst < 1 || nprim < 1 || nmat < 1) return NULL;
+    return pto_scene_create_textured(mats, nmat, prims, nprim, insts, ninst, cam, background, NULL, 0, NULL, 0, -1);
+}
+pto_scene *pto_scene_create_textured(const pto_material *mats, int nmat, const pto_prim *prims, int nprim,
+                                     const pto_instance *insts, int ninst, const pto_camera *cam,
+                                     const float background[3], const pto_texture *tex, int ntex,
+                                     const uint8_t *texels, int64_t texel_bytes, int background_texture)
+{
+    if (ninst < 1 || nprim < 1 || nmat < 1 || ntex < 0 || background_texture >= ntex) return NULL;
     pto_scene *sc = (pto_scene *)calloc(1, sizeof(*sc));
+    sc->ntex = ntex;
+    sc->background_tex = background_texture < 0 ? -1 : background_texture;
+    sc->tex = (tex_t *)calloc((size_t)ntex + 1, sizeof(tex_t));
+    sc->texels = (uint8_t *)malloc((size_t)(texel_bytes > 0 ? texel_bytes : 1));
+    if (texel_bytes > 0) memcpy(sc->texels, texels, (size_t)texel_bytes);
+    for (int i = 0; i < ntex; i++) {
+        tex_t *t = &sc->tex[i];
+        t->type = tex[i].type;
+        t->color = V(tex[i].color[0], tex[i].color[1], tex[i].color[2]);
+        t->alpha = tex[i].alpha;
+        t->even = tex[i].even; t->odd = tex[i].odd; t->scale = tex[i].scale;
+        t->width = tex[i].width; t->height = tex[i].height;
+        if (t->type == PTO_TEX_CHECKER && (t->even < 0 || t->even >= i || t->odd < 0 || t->odd >= i)) goto fail;
+        if (t->type == PTO_TEX_IMAGE) {
+            if (t->width < 1 || t->height < 1 || tex[i].texel_offset < 0 ||
+                tex[i].texel_offset + 4 * (int64_t)t->width * t->height > texel_bytes) goto fail;
+            t->rgba = sc->texels + tex[i].texel_offset;
+        }
+        if (t->type < PTO_TEX_CONSTANT || t->type > PTO_TEX_IMAGE) goto fail;
+    }
     sc->nmat = nmat; sc->nprim = nprim; sc->ninst = ninst;
     sc->mats = (mat_t *)calloc((size_t)nmat, sizeof(mat_t));
     sc->prims = (prim_t *)calloc((size_t)nprim, sizeof(prim_t));
@@ -706,6 +801,9 @@ pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *
         sc->mats[i].alpha = mats[i].alpha;
         sc->mats[i].power = mats[i].power;
         sc->mats[i].two_sided = mats[i].two_sided;
+        sc->mats[i].tex = mats[i].texture;
+        if (mats[i].texture >= ntex) goto fail;
+        if (mats[i].texture < 0) sc->mats[i].tex = -1;
     }
     for (int i = 0; i < nprim; i++) {
         const pto_prim *p = &prims[i];
@@ -766,7 +864,7 @@ pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *
         if (p->is_light) sc->lights[sc->nlight++] = i;
     }
     mt_seed(&sc->rng, 5489u);
-    for (int i = 0; i < PERLIN_STATIC_DRAWS; i++) (void)mt_double(&sc->rng);
+    perlin_static_init(&sc->rng, sc->ranvec, sc->perm); /* consumes the PERLIN_STATIC_DRAWS values */
     {
         int *order = (int *)malloc((size_t)ninst * sizeof(int));
         int *tmp = (int *)malloc((size_t)ninst * sizeof(int));
@@ -784,6 +882,7 @@ void pto_scene_destroy(pto_scene *s)
 {
     if (!s) return;
     free(s->mats); free(s->prims); free(s->insts); free(s->nodes); free(s->lights);
+    free(s->tex); free(s->texels);
     free(s);
 }
 int pto_scene_num_instances(const pto_scene *s) { return s->ninst; }
@@ -960,11 +1059,127 @@ static v3 material_generate(const mat_t *m, v3 normal, rngctx *rc, uint32_t dim)
     }
     return random_in_unit_sphere(rc, dim); /* isotropic material.h:267-270 (and void_pdf) */
 }
-static v3 material_emitted(const mat_t *m, v3 ray_dir, v3 normal)
+/* ---- textures (texture.h, image.h) -------------------------------------------------------- */
+/* perlin_generate / perlin_generate_perm / permute (texture.h:76-110) in static-initialisation order (:180-183):
+ * ranvec (256 x 3 draws), then perm_x, perm_y, perm_z (255 draws each) = the 1533 draws before main(). */
+static void perlin_static_init(mt19937 *g, v3 ranvec[256], int perm[3][256])
+{
+    for (int i = 0; i < 256; i++) {
+        double xr = 2 * mt_double(g) - 1;
+        double yr = 2 * mt_double(g) - 1;
+        double zr = 2 * mt_double(g) - 1;
+        ranvec[i] = vunit(V((float)xr, (float)yr, (float)zr));
+    }
+    for (int k = 0; k < 3; k++) {
+        int *p = perm[k];
+        for (int i = 0; i < 256; i++) p[i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = (int)(mt_double(g) * (i + 1));
+            int tmp = p[i];
+            p[i] = p[target];
+            p[target] = tmp;
+        }
+    }
+}
+void pto_perlin_tables(float ranvec[768], int32_t perm[768])
+{
+    mt19937 g;
+    v3 rv[256];
+    int pm[3][256];
+    mt_seed(&g, 5489u);
+    perlin_static_init(&g, rv, pm);
+    for (int i = 0; i < 256; i++) { ranvec[3 * i] = rv[i].x; ranvec[3 * i + 1] = rv[i].y; ranvec[3 * i + 2] = rv[i].z; }
+    for (int k = 0; k < 3; k++)
+        for (int i = 0; i < 256; i++) perm[k * 256 + i] = pm[k][i];
+}
+/* perlin::noise (texture.h:134-160) + perlin_interp (:111-131): the Hermite smoothing is applied in noise() AND again in
+ * perlin_interp(), whose weight vector also uses the already-smoothed u, v, w -- restated as written. */
+static float perlin_noise(const pto_scene *sc, v3 p)
+{
+    float u = p.x - floorf(p.x);
+    float v = p.y - floorf(p.y);
+    float w = p.z - floorf(p.z);
+    u = u * u * (3 - 2 * u);
+    v = v * v * (3 - 2 * v);
+    w = w * w * (3 - 2 * w);
+    int i = (int)floorf(p.x);
+    int j = (int)floorf(p.y);
+    int k = (int)floorf(p.z);
+    float uu = u * u * (3 - 2 * u);
+    float vv = v * v * (3 - 2 * v);
+    float ww = w * w * (3 - 2 * w);
+    float accum = 0;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                v3 c = sc->ranvec[sc->perm[0][(i + di) & 255] ^ sc->perm[1][(j + dj) & 255] ^ sc->perm[2][(k + dk) & 255]];
+                v3 weight_v = V(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) *
+                         vdot(c, weight_v);
+            }
+    return accum;
+}
+/* texture::value(u, v, p) and ::alpha(u, v, p).  checker_texture picks the same child for both (texture.h:43-68). */
+static void tex_eval(const pto_scene *sc, int ti, float u, float v, v3 p, int mode, v3 *color, float *alpha)
+{
+    for (;;) {
+        const tex_t *t = &sc->tex[ti];
+        if (t->type == PTO_TEX_CHECKER) { /* sines(): texture.h:70-73, sin(float) = sinf */
+            float sx, sy, sz;
+            if (mode == PTO_MODE_MT) { sx = sinf(t->scale * p.x); sy = sinf(t->scale * p.y); sz = sinf(t->scale * p.z); }
+            else { sx = ptm_sinf(t->scale * p.x); sy = ptm_sinf(t->scale * p.y); sz = ptm_sinf(t->scale * p.z); }
+            ti = (sx * sy * sz > 0) ? t->odd : t->even;
+            continue;
+        }
+        if (t->type == PTO_TEX_PERLIN) { /* noise_texture::value texture.h:190-193; alpha(): base class, 1.0 */
+            float n = perlin_noise(sc, vscale(t->scale, p));
+            *color = V(1 * n, 1 * n, 1 * n);
+            *alpha = 1.0f;
+            return;
+        }
+        if (t->type == PTO_TEX_IMAGE) { /* image.h:15-49 */
+            v -= (int)v;
+            if (v < 0) v += 1;
+            u -= (int)u;
+            if (u < 0) u += 1;
+            int y = (int)(v * t->height);
+            int x = (int)(u * t->width);
+            if (y > t->height - 1) y = t->height - 1; /* u or v == 1.0f after the wrap: the reference reads out of bounds */
+            if (x > t->width - 1) x = t->width - 1;
+            const uint8_t *px = t->rgba + 4 * ((size_t)y * t->width + x);
+            *color = V((float)(px[0] / 255.0), (float)(px[1] / 255.0), (float)(px[2] / 255.0)); /* image.h:58-62 */
+            *alpha = (float)(px[3] / 255.0);
+            return;
+        }
+        *color = t->color;
+        *alpha = t->alpha;
+        return;
+    }
+}
+void pto_texture_eval(const pto_scene *s, int ti, int mode, float u, float v, const float p[3], float out[4])
+{
+    v3 c = V(0, 0, 0);
+    float a = 0;
+    if (ti >= 0 && ti < s->ntex) tex_eval(s, ti, u, v, V(p[0], p[1], p[2]), mode, &c, &a);
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = a;
+}
+/* albedo->value(rec.u, rec.v, rec.p) of a lambertian / isotropic (material.h:44, 259) */
+static v3 material_albedo(const pto_scene *sc, const mat_t *m, const hitrec *rec, int mode)
+{
+    if (m->tex < 0) return m->color;
+    v3 c; float a;
+    tex_eval(sc, m->tex, rec->u, rec->v, rec->p, mode, &c, &a);
+    return c;
+}
+static v3 material_emitted(const pto_scene *sc, const mat_t *m, v3 ray_dir, const hitrec *rec, int mode)
 {   /* material.h:211-229; everything else material.h:21-24 (isotropic's 3-arg emitted never overrides) */
     if (m->type != PTO_MAT_DIFFUSE_LIGHT) return V(0, 0, 0);
-    int aligned = vdot(normal, ray_dir) > 0;
-    if (!aligned || m->two_sided) return vscale(m->alpha, vscale(m->power, m->color));
+    int aligned = vdot(rec->normal, ray_dir) > 0;
+    if (!aligned || m->two_sided) {
+        v3 c = m->color; float a = m->alpha;
+        if (m->tex >= 0) tex_eval(sc, m->tex, rec->u, rec->v, rec->p, mode, &c, &a);   /* emitted(r, rec, rec.u, rec.v, rec.p) */
+        return vscale(a, vscale(m->power, c));
+    }
     return V(0, 0, 0);
 }
 
@@ -993,16 +1208,16 @@ static v3 integrator_color(const pto_scene *sc, const pto_config *cfg, ray_t r, 
             int did_scatter = 1;
             switch (m->type) {
             case PTO_MAT_LAMBERTIAN:
-                if (vdot(r.B, rec.normal) < 0) attenuation = vdivf(m->color, (float)M_PI);
+                if (vdot(r.B, rec.normal) < 0) attenuation = vdivf(material_albedo(sc, m, &rec, mode), (float)M_PI);
                 else attenuation = V(0, 0, 0);
                 break;
             case PTO_MAT_METAL: attenuation = vdivf(m->color, (float)M_PI); break;
             case PTO_MAT_DIELECTRIC: attenuation = V(1.0f, 1.0f, 1.0f); break;
             case PTO_MAT_DIFFUSE_LIGHT: did_scatter = 0; break;
-            case PTO_MAT_ISOTROPIC: attenuation = m->color; break;
+            case PTO_MAT_ISOTROPIC: attenuation = material_albedo(sc, m, &rec, mode); break;
             }
             float cos_i = fabsf(vdot(vunit(r.B), vunit(rec.normal)));
-            hit_emission = material_emitted(m, r.B, rec.normal);
+            hit_emission = material_emitted(sc, m, r.B, &rec, mode);
             if (vsqlen(hit_emission) > 0.000001) {
                 if (last_bsdf_pdf <= 0) {
                     sum = vadd(sum, vmul(beta, hit_emission));
@@ -1031,7 +1246,7 @@ static v3 integrator_color(const pto_scene *sc, const pto_config *cfg, ray_t r, 
                 int did_light_hit = world_hit(sc, &light_ray, &lrec, rc);
                 ctr->rays++; ctr->shadow_rays++;
                 if (did_light_hit && (double)vlen(attenuation) > 0.0001) {
-                    v3 le = material_emitted(&sc->mats[lrec.mat], light_ray.B, lrec.normal);
+                    v3 le = material_emitted(sc, &sc->mats[lrec.mat], light_ray.B, &lrec, mode);
                     float dropoff = (mode == PTO_MODE_MT) ? (float)fmax((double)cos_l, 0.0) : (cos_l > 0.0f ? cos_l : 0.0f);
                     /* attenuation * beta * weight_l / light_pdf_l * dropoff * light_emission / pick_pdf */
                     v3 c = vmul(attenuation, beta);
@@ -1070,8 +1285,22 @@ static v3 integrator_color(const pto_scene *sc, const pto_config *cfg, ray_t r, 
                 break;
             }
         } else {
-            /* constant background: world.h:27-30 -> texture.h:21-24 ignores (u, v, p) */
-            sum = vadd(sum, vmul(beta, sc->background));
+            /* integrator.h:325-336: world->value(u, v, unit_direction); a constant background ignores all three
+               (world.h:27-30 -> texture.h:21-24).  TAU is "2 * M_PI" unparenthesised (random.h:7), so u = ((pi + atan2) / 2) * pi */
+            v3 bg = sc->background;
+            if (sc->background_tex >= 0) {
+                v3 ud = vunit(r.B);
+                float eu, ev, a;
+                if (mode == PTO_MODE_MT) {
+                    eu = (float)((M_PI + (double)atan2f(ud.y, ud.x)) / 2 * M_PI);
+                    ev = (float)((double)acosf(ud.z) / M_PI);
+                } else {
+                    eu = (float)((M_PI + (double)ptm_atan2f(ud.y, ud.x)) / 2 * M_PI);
+                    ev = (float)((double)ptm_acosf(ud.z) / M_PI);
+                }
+                tex_eval(sc, sc->background_tex, eu, ev, ud, mode, &bg, &a);
+            }
+            sum = vadd(sum, vmul(beta, bg));
             ctr->term_miss++;
             break;
         }

@@ -25,6 +25,7 @@ extern "C" {
 enum { PTO_MAT_LAMBERTIAN = 0, PTO_MAT_METAL = 1, PTO_MAT_DIELECTRIC = 2, PTO_MAT_DIFFUSE_LIGHT = 3, PTO_MAT_ISOTROPIC = 4 };
 enum { PTO_PRIM_RECT = 0, PTO_PRIM_BOX = 1, PTO_PRIM_SPHERE = 2, PTO_PRIM_VOLUME = 3 };
 enum { PTO_PLANE_XY = 0, PTO_PLANE_XZ = 1, PTO_PLANE_YZ = 2 };
+enum { PTO_TEX_CONSTANT = 0, PTO_TEX_CHECKER = 1, PTO_TEX_PERLIN = 2, PTO_TEX_IMAGE = 3 };
 
 typedef struct {
     int32_t type;
@@ -32,7 +33,19 @@ typedef struct {
     float alpha, power;
     int32_t two_sided;
     float fuzz, ior;
+    int32_t texture; /* albedo / emit texture (index into the texture table) when it is not a constant one, else -1 */
 } pto_material;
+
+/* texture.h: constant_texture :14-31, checker_texture :33-75, noise_texture :185-196; image.h:7-50 */
+typedef struct {
+    int32_t type;
+    float color[3];
+    float alpha;
+    int32_t even, odd; /* checker: texture indices (smaller than this texture's own index) */
+    float scale;       /* checker, perlin */
+    int32_t width, height;
+    int64_t texel_offset; /* image: byte offset of its RGBA8 pixels (row 0 first) in the texel blob */
+} pto_texture;
 
 typedef struct {
     int32_t type, mat;
@@ -77,7 +90,16 @@ typedef struct pto_scene pto_scene;
 pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *prims, int nprim,
                             const pto_instance *insts, int ninst, const pto_camera *cam,
                             const float background[3]);
+/* Same with a texture table: the Perlin tables are the ones the 1533 static-init draws produce. */
+pto_scene *pto_scene_create_textured(const pto_material *mats, int nmat, const pto_prim *prims, int nprim,
+                                     const pto_instance *insts, int ninst, const pto_camera *cam,
+                                     const float background[3], const pto_texture *tex, int ntex,
+                                     const uint8_t *texels, int64_t texel_bytes, int background_texture);
 void pto_scene_destroy(pto_scene *s);
+/* perlin::ranvec (256 x 3) and perm_x / perm_y / perm_z (256 each) after static init (texture.h:180-183) */
+void pto_perlin_tables(float ranvec[768], int32_t perm[768]);
+/* texture value(u, v, p) and alpha(u, v, p) of texture `ti` (MT mode: libm sinf; stream mode: ptm_sinf): out = r g b alpha */
+void pto_texture_eval(const pto_scene *s, int ti, int mode, float u, float v, const float p[3], float out[4]);
 
 /* tables for comparison with oracle/_ref and with the product's flattened scene */
 int pto_scene_num_instances(const pto_scene *s);
@@ -124,6 +146,9 @@ void pto_world_hit_stream(const pto_scene *s, int64_t n, const float *origins, c
 void ptm_sincos_2pi(float r, float *s, float *c);
 float ptm_cbrtf(float x);
 float ptm_logf(float x);
+float ptm_sinf(float x);
+float ptm_atan2f(float y, float x);
+float ptm_acosf(float x);
 
 #ifdef __cplusplus
 }

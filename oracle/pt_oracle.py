@@ -21,7 +21,13 @@ MODE_MT, MODE_STREAM = 0, 1
 
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("alpha", C.c_float), ("power", C.c_float),
-                ("two_sided", C.c_int32), ("fuzz", C.c_float), ("ior", C.c_float)]
+                ("two_sided", C.c_int32), ("fuzz", C.c_float), ("ior", C.c_float), ("texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("alpha", C.c_float), ("even", C.c_int32),
+                ("odd", C.c_int32), ("scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("texel_offset", C.c_int64)]
 
 
 class Prim(C.Structure):
@@ -71,6 +77,17 @@ def lib():
         L.pto_scene_create.restype = C.c_void_p
         L.pto_scene_create.argtypes = [C.POINTER(Material), C.c_int, C.POINTER(Prim), C.c_int, C.POINTER(Instance),
                                        C.c_int, C.POINTER(Camera), C.POINTER(C.c_float)]
+        L.pto_scene_create_textured.restype = C.c_void_p
+        L.pto_scene_create_textured.argtypes = L.pto_scene_create.argtypes + [C.POINTER(Texture), C.c_int, C.c_char_p,
+                                                                            C.c_int64, C.c_int]
+        L.pto_perlin_tables.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.pto_texture_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_float)]
+        for name in ("ptm_sinf", "ptm_acosf"):
+            getattr(L, name).argtypes = [C.c_float]
+            getattr(L, name).restype = C.c_float
+        L.ptm_atan2f.argtypes = [C.c_float, C.c_float]
+        L.ptm_atan2f.restype = C.c_float
         L.pto_scene_destroy.argtypes = [C.c_void_p]
         for name in ("pto_scene_num_instances", "pto_scene_num_nodes", "pto_scene_num_lights"):
             getattr(L, name).argtypes = [C.c_void_p]
@@ -126,6 +143,7 @@ class Scene:
             d.type = m.type
             d.color[:] = [float(x) for x in m.color]
             d.alpha, d.power, d.two_sided, d.fuzz, d.ior = float(m.alpha), float(m.power), int(m.two_sided), float(m.fuzz), float(m.ior)
+            d.texture = m.texture
         prims = (Prim * len(params.prims))()
         for d, p in zip(prims, params.prims):
             d.type, d.mat = p.type, p.mat
@@ -148,7 +166,17 @@ class Scene:
         cam.look_at[:] = [float(x) for x in c.look_at]
         cam.fov, cam.aperture, cam.dist_to_focus = float(c.fov), float(c.aperture), float(c.dist_to_focus)
         bg = (C.c_float * 3)(*[float(x) for x in params.background])
-        self._h = lib().pto_scene_create(mats, len(mats), prims, len(prims), insts, len(insts), C.byref(cam), bg)
+        texs = (Texture * max(len(params.textures), 1))()
+        blob = b""
+        for d, t in zip(texs, params.textures):
+            d.type = t.type
+            d.color[:] = [float(x) for x in t.color]
+            d.alpha, d.even, d.odd, d.scale, d.width, d.height = float(t.alpha), t.even, t.odd, float(t.scale), t.width, t.height
+            if t.type == sp.TEX_IMAGE:
+                d.texel_offset = len(blob)
+                blob += t.rgba
+        self._h = lib().pto_scene_create_textured(mats, len(mats), prims, len(prims), insts, len(insts), C.byref(cam), bg,
+                                                  texs, len(params.textures), blob, len(blob), params.background_texture)
         if not self._h:
             raise ValueError("pto_scene_create rejected the scene")
 
@@ -193,6 +221,15 @@ class Scene:
     def camera(self, width, height):
         out = np.zeros(22, np.float32)
         lib().pto_scene_camera(self._h, width, height, _fp(out))
+        return out
+
+    def texture_eval(self, ti, uvp, mode=MODE_MT):
+        """value (rgb) and alpha of texture `ti` at rows (u, v, px, py, pz)."""
+        q = np.ascontiguousarray(uvp, np.float32).reshape(-1, 5)
+        out = np.zeros((len(q), 4), np.float32)
+        for k in range(len(q)):
+            p = (C.c_float * 3)(*q[k, 2:5])
+            lib().pto_texture_eval(self._h, ti, mode, float(q[k, 0]), float(q[k, 1]), p, _fp(out[k]))
         return out
 
     def next_random(self) -> float:
@@ -248,6 +285,14 @@ class Scene:
         ctr = Counters()
         lib().pto_sample_stream(self._h, C.byref(cfg), seed, i, j, s, _fp(rgb), C.byref(ctr))
         return rgb, ctr.as_dict()
+
+
+def perlin_tables():
+    """(ranvec 256x3 float32, perm 3x256 int32) as the reference's static initialisers leave them."""
+    rv = np.zeros((256, 3), np.float32)
+    pm = np.zeros((3, 256), np.int32)
+    lib().pto_perlin_tables(_fp(rv), pm.ctypes.data_as(C.POINTER(C.c_int32)))
+    return rv, pm
 
 
 def rng_after_static_init(n: int) -> np.ndarray:

@@ -26,6 +26,7 @@
 #include "helpers.h"
 #include "hittable_list.h"
 #include "material.h"
+#include "image.h"
 #include "pdf.h"
 #include "primitive.h"
 #include "random.h"
@@ -54,6 +55,8 @@ static float hx(std::istringstream &ss)
 
 struct Built
 {
+    std::vector<texture *> textures;
+    int background_texture = -1;
     std::vector<material *> materials;
     std::vector<hittable *> prims;
     std::vector<hittable *> list; // BVH input order (file order)
@@ -89,6 +92,41 @@ static Built build(const char *path)
             float r = hx(ss), g = hx(ss), bl = hx(ss);
             b.background = vec3(r, g, bl);
         }
+        else if (kind == "texture")
+        {
+            std::string t;
+            ss >> t;
+            if (t == "constant")
+            {
+                float r = hx(ss), g = hx(ss), bl = hx(ss), alpha = hx(ss);
+                b.textures.push_back(new constant_texture(vec3(r, g, bl), alpha));
+            }
+            else if (t == "checker")
+            {
+                int even, odd;
+                ss >> even >> odd;
+                float scale = hx(ss);
+                b.textures.push_back(new checker_texture(b.textures[even], b.textures[odd], scale));
+            }
+            else if (t == "perlin")
+            {
+                b.textures.push_back(new noise_texture(hx(ss)));
+            }
+            else if (t == "image")
+            {
+                int w, h;
+                std::string hex;
+                ss >> w >> h >> hex;
+                std::vector<unsigned char> px(hex.size() / 2);
+                for (size_t i = 0; i < px.size(); i++)
+                    px[i] = (unsigned char)strtol(hex.substr(2 * i, 2).c_str(), nullptr, 16);
+                b.textures.push_back(from_4byte_vector(px, w, h)); // what decode_into_texture does after lodepng
+            }
+        }
+        else if (kind == "background_texture")
+        {
+            ss >> b.background_texture;
+        }
         else if (kind == "material")
         {
             int type;
@@ -97,8 +135,20 @@ static Built build(const char *path)
             int two_sided;
             ss >> two_sided;
             float fuzz = hx(ss), ior = hx(ss);
+            int tex = -1;
+            ss >> tex;
             vec3 col(r, g, bl);
             material *m = nullptr;
+            if (tex >= 0 && type == 0)
+            {
+                b.materials.push_back(new lambertian(b.textures[tex]));
+                continue;
+            }
+            if (tex >= 0 && type == 3)
+            {
+                b.materials.push_back(new diffuse_light(b.textures[tex], power, two_sided != 0));
+                continue;
+            }
             switch (type)
             {
             case 0:
@@ -173,7 +223,7 @@ static Built build(const char *path)
     }
     b.list_sorted = b.list; // bvh_node's qsort permutes the array it is given
     bvh_node *root = new bvh_node(b.list_sorted.data(), (int)b.list_sorted.size(), 0.0f, 0.0f);
-    b.world = new World(root, new constant_texture(b.background), b.lights);
+    b.world = new World(root, b.background_texture >= 0 ? b.textures[b.background_texture] : (texture *)new constant_texture(b.background), b.lights);
     return b;
 }
 
@@ -256,7 +306,49 @@ int main(int argc, char **argv)
         fclose(f);
         return 0;
     }
+    if (mode == "perlin")
+    {   // the static tables of texture.h:180-183 as the reference's own static initialisers left them
+        FILE *f = fopen(argv[3], "wb");
+        for (int i = 0; i < 256; i++)
+        {
+            float v[3] = {perlin::ranvec[i][0], perlin::ranvec[i][1], perlin::ranvec[i][2]};
+            fwrite(v, sizeof(float), 3, f);
+        }
+        int *perms[3] = {perlin::perm_x, perlin::perm_y, perlin::perm_z};
+        for (int k = 0; k < 3; k++)
+            for (int i = 0; i < 256; i++)
+            {
+                float v = (float)perms[k][i];
+                fwrite(&v, sizeof(float), 1, f);
+            }
+        fclose(f);
+        return 0;
+    }
     Built b = build(argv[1]);
+    if (mode == "texeval")
+    {   // texeval points.f32 n out.f32: every texture's value(u,v,p) and alpha(u,v,p) at n points (u v px py pz)
+        int n = atoi(argv[4]);
+        std::vector<float> pts((size_t)n * 5);
+        FILE *fi = fopen(argv[3], "rb");
+        if (!fi || fread(pts.data(), sizeof(float), pts.size(), fi) != pts.size())
+        {
+            fprintf(stderr, "cannot read %s\n", argv[3]);
+            return 2;
+        }
+        fclose(fi);
+        FILE *f = fopen(argv[5], "wb");
+        for (texture *t : b.textures)
+            for (int i = 0; i < n; i++)
+            {
+                const float *q = &pts[(size_t)i * 5];
+                vec3 p(q[2], q[3], q[4]);
+                vec3 c = t->value(q[0], q[1], p);
+                float out[4] = {c[0], c[1], c[2], t->alpha(q[0], q[1], p)};
+                fwrite(out, sizeof(float), 4, f);
+            }
+        fclose(f);
+        return 0;
+    }
     if (mode == "tables")
     {
         FILE *f = fopen(argv[3], "w");

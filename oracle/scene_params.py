@@ -18,6 +18,7 @@ compared against each other in tests/test_scene_flatten.py.
 from __future__ import annotations
 
 import json
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -32,6 +33,9 @@ PRIM_RECT, PRIM_BOX, PRIM_SPHERE, PRIM_VOLUME = 0, 1, 2, 3
 # rect plane codes: reference primitive.h:11-16 (enum plane_enum { XY, XZ, YZ })
 PLANE_XY, PLANE_XZ, PLANE_YZ = 0, 1, 2
 
+# texture type codes (reference scene.h:63-69 texture_type)
+TEX_CONSTANT, TEX_CHECKER, TEX_PERLIN, TEX_IMAGE = 0, 1, 2, 3
+
 MAUVE = (F(0.8), F(0.2), F(0.8))  # scene_parser.h:16
 
 
@@ -44,6 +48,20 @@ def vec3(a):
 
 
 @dataclass
+class Texture:
+    """texture.h: constant_texture :14-31, checker_texture :33-75, noise_texture :185-196; image.h:7-50 image_texture."""
+    type: int
+    color: tuple = (F(0), F(0), F(0))
+    alpha: np.float32 = F(1.0)
+    even: int = -1          # checker: texture indices
+    odd: int = -1
+    scale: np.float32 = F(1.0)
+    width: int = 0          # image: decoded RGBA8, row 0 first (lodepng order)
+    height: int = 0
+    rgba: Optional[bytes] = None
+
+
+@dataclass
 class Material:
     type: int
     color: tuple = (F(0), F(0), F(0))
@@ -53,6 +71,7 @@ class Material:
     fuzz: np.float32 = F(0.0)
     ior: np.float32 = F(1.45)
     json_type: str = "lambertian"  # the *type string* the parser keeps (light test, scene_parser.h:541)
+    texture: int = -1       # index into SceneParams.textures when albedo / emit is not a constant texture
 
 
 @dataclass
@@ -100,16 +119,20 @@ class SceneParams:
     instances: List[Instance] = field(default_factory=list)
     camera: Optional[Camera] = None
     background: tuple = MAUVE
+    textures: List[Texture] = field(default_factory=list)
+    background_texture: int = -1   # World::background when it is not a constant texture
 
 
 class _Builder:
     def __init__(self):
         self.sp = SceneParams()
-        self.textures: Dict[str, tuple] = {}      # id -> (color, alpha)
+        self.textures: Dict[str, int] = {}        # id -> index into sp.textures
+        self.base_dir = "."
         self.materials: Dict[str, int] = {}       # id -> material index
         self.prims: Dict[str, int] = {}           # id -> prim index (-1 = null hittable)
         self.last_id = 0
         self._error_mat: Optional[int] = None
+        self._error_tex: Optional[int] = None
 
     # scene_parser.h:20-24 / 92-96: one shared mauve lambertian
     def error_material(self) -> int:
@@ -128,21 +151,50 @@ class _Builder:
         if mid not in self.materials:
             self.materials[mid] = idx
 
+    def add_texture(self, t: Texture) -> int:
+        self.sp.textures.append(t)
+        return len(self.sp.textures) - 1
+
+    def error_texture(self) -> int:   # scene_parser.h:98-102: one shared mauve constant texture
+        if self._error_tex is None:
+            self._error_tex = self.add_texture(Texture(TEX_CONSTANT, MAUVE))
+        return self._error_tex
+
     def parse_textures(self, scene):
+        """scene_parser.h:263-330; std::map::emplace keeps the first entry on duplicate ids."""
         for el in scene.get("textures", []) or []:
             if el.get("skip", False):
                 continue
             tid = el["id"]
             if "data" not in el:
-                self.textures.setdefault(tid, (MAUVE, F(1.0)))
+                self.textures.setdefault(tid, self.error_texture())
                 continue
-            ttype = el["type"]
+            data = el["data"]
+            ttype = el["type"] if el["type"] in ("constant", "checker", "perlin", "png") else "constant"   # scene.h:71-79
             if ttype == "constant":
-                data = el["data"]
-                self.textures.setdefault(tid, (vec3(data["color"]), f32(data.get("alpha", 1.0))))
+                idx = self.add_texture(Texture(TEX_CONSTANT, vec3(data["color"]), f32(data.get("alpha", 1.0))))
+            elif ttype == "checker":
+                def child(d):
+                    if "texture" in d:
+                        return self.textures[d["texture"]]
+                    return self.add_texture(Texture(TEX_CONSTANT, vec3(d["color"])))
+                odd = child(data["odd"])       # scene_parser.h:292-309: odd first, then even
+                even = child(data["even"])
+                idx = self.add_texture(Texture(TEX_CHECKER, even=even, odd=odd, scale=f32(data["scale"])))
+            elif ttype == "perlin":
+                idx = self.add_texture(Texture(TEX_PERLIN, scale=f32(data.get("scale", 1.0))))
             else:
-                raise NotImplementedError(
-                    f"texture type {ttype!r} is outside the hot-path scope (SURVEY.md 8f-4)")
+                w, h, rgba = decode_png(os.path.join(self.base_dir, data["path"]))
+                idx = self.add_texture(Texture(TEX_IMAGE, width=w, height=h, rgba=rgba))
+            self.textures.setdefault(tid, idx)
+
+    def texture_ref(self, tid: str):
+        """(inline colour, alpha, texture index): constant textures are folded into the material like before."""
+        idx = self.textures[tid]
+        t = self.sp.textures[idx]
+        if t.type == TEX_CONSTANT:
+            return t.color, t.alpha, -1
+        return (F(0), F(0), F(0)), F(1.0), idx
 
     def parse_materials(self, scene):
         for el in scene.get("materials", []) or []:
@@ -161,8 +213,8 @@ class _Builder:
                 if "color" in data:
                     m = Material(MAT_LAMBERTIAN, vec3(data["color"]), json_type="lambertian")
                 elif "texture" in data:
-                    col, a = self.textures[data["texture"]]
-                    m = Material(MAT_LAMBERTIAN, col, alpha=a, json_type="lambertian")
+                    col, a, ti = self.texture_ref(data["texture"])
+                    m = Material(MAT_LAMBERTIAN, col, alpha=a, json_type="lambertian", texture=ti)
                 else:
                     self.add_material(mid, self.error_material())
                     continue
@@ -178,11 +230,11 @@ class _Builder:
                 power = f32(data["power"]) if "power" in data else F(1.0)
                 two_sided = bool(data.get("two_sided", True))
                 if "texture" in data:
-                    col, a = self.textures[data["texture"]]
+                    col, a, ti = self.texture_ref(data["texture"])
                 else:
-                    col, a = (vec3(data["color"]) if "color" in data else (F(1), F(1), F(1))), F(1.0)
+                    col, a, ti = (vec3(data["color"]) if "color" in data else (F(1), F(1), F(1))), F(1.0), -1
                 m = Material(MAT_DIFFUSE_LIGHT, col, alpha=a, power=power, two_sided=two_sided,
-                             json_type="diffuse_light")
+                             json_type="diffuse_light", texture=ti)
             else:  # "isotropic": the reference's switch has no case for it (scene_parser.h:444)
                 continue
             self.sp.materials.append(m)
@@ -272,7 +324,8 @@ class _Builder:
         w = scene.get("world")
         if w is not None:
             if "texture" in w:
-                self.sp.background = self.textures[w["texture"]][0]
+                col, _, ti = self.texture_ref(w["texture"])
+                self.sp.background, self.sp.background_texture = col, ti
             elif "color" in w:
                 self.sp.background = vec3(w["color"])
             else:
@@ -283,13 +336,102 @@ class _Builder:
         return self.sp
 
 
-def load_scene_params(path_or_dict) -> SceneParams:
+def load_scene_params(path_or_dict, base_dir: Optional[str] = None) -> SceneParams:
+    """base_dir: directory that relative PNG paths are resolved against (the reference resolves them against its
+    working directory); defaults to the parent of the scene file's directory, i.e. the repo root for scenes/*.json."""
+    b = _Builder()
     if isinstance(path_or_dict, (str, bytes)):
         with open(path_or_dict) as f:
             scene = json.load(f)
+        b.base_dir = base_dir or os.path.dirname(os.path.dirname(os.path.abspath(path_or_dict)))
     else:
         scene = path_or_dict
-    return _Builder().build(scene)
+        b.base_dir = base_dir or "."
+    return b.build(scene)
+
+
+def decode_png(path: str):
+    """What lodepng::decode(image, w, h, path) hands to from_4byte_vector (scene_parser.h:39-55): RGBA8, row 0 first.
+    lodepng 's own code is not vendored in the reference; this is a plain PNG reader (zlib from the Python stdlib) for
+    non-interlaced 8-bit grey / grey+alpha / RGB / RGBA / palette images -- the test-side twin of the product's reader."""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    if raw[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG: " + path)
+    pos, idat, plte, trns, hdr = 8, b"", None, None, None
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"PLTE":
+            plte = body
+        elif typ == b"tRNS":
+            trns = body
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if depth != 8 or interlace != 0 or ctype not in (0, 2, 3, 4, 6):
+        raise NotImplementedError("PNG: only non-interlaced 8-bit images are supported")
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    data = zlib.decompress(idat)
+    stride = w * ch
+    rows = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    p = 0
+    for y in range(h):
+        ft = data[p]
+        line = np.frombuffer(data, np.uint8, stride, p + 1).astype(np.int32)
+        p += 1 + stride
+        cur = np.zeros(stride, np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            for i in range(stride):
+                a = cur[i - ch] if i >= ch else 0
+                b = prev[i]
+                c = prev[i - ch] if i >= ch else 0
+                if ft == 1:
+                    pr = a
+                elif ft == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pr) & 255
+        rows[y] = cur
+        prev = cur
+    px = rows.reshape(h, w, ch)
+    out = np.zeros((h, w, 4), np.uint8)
+    out[..., 3] = 255
+    if ctype == 0:
+        out[..., 0] = out[..., 1] = out[..., 2] = px[..., 0]
+        if trns is not None and len(trns) >= 2:
+            out[..., 3] = np.where(px[..., 0] == trns[1], 0, 255)
+    elif ctype == 4:
+        out[..., 0] = out[..., 1] = out[..., 2] = px[..., 0]
+        out[..., 3] = px[..., 1]
+    elif ctype == 2:
+        out[..., :3] = px
+        if trns is not None and len(trns) >= 6:
+            key = np.array([trns[1], trns[3], trns[5]], np.uint8)
+            out[..., 3] = np.where((px == key).all(axis=2), 0, 255)
+    elif ctype == 6:
+        out[...] = px
+    else:
+        pal = np.frombuffer(plte, np.uint8).reshape(-1, 3)
+        al = np.full(len(pal), 255, np.uint8)
+        if trns is not None:
+            al[:len(trns)] = np.frombuffer(trns, np.uint8)[:len(pal)]
+        out[..., :3] = pal[px[..., 0]]
+        out[..., 3] = al[px[..., 0]]
+    return w, h, out.tobytes()
 
 
 def _hx(x) -> str:
@@ -302,9 +444,20 @@ def to_text(sp: SceneParams) -> str:
     c = sp.camera
     out.append("camera " + " ".join(_hx(v) for v in (*c.look_from, *c.look_at, c.fov, c.aperture, c.dist_to_focus)))
     out.append("background " + " ".join(_hx(v) for v in sp.background))
+    for t in sp.textures:   # before the materials that refer to them; children before their checker
+        if t.type == TEX_CONSTANT:
+            out.append("texture constant %s %s" % (" ".join(_hx(v) for v in t.color), _hx(t.alpha)))
+        elif t.type == TEX_CHECKER:
+            out.append("texture checker %d %d %s" % (t.even, t.odd, _hx(t.scale)))
+        elif t.type == TEX_PERLIN:
+            out.append("texture perlin %s" % _hx(t.scale))
+        else:
+            out.append("texture image %d %d %s" % (t.width, t.height, t.rgba.hex()))
+    if sp.background_texture >= 0:
+        out.append("background_texture %d" % sp.background_texture)
     for m in sp.materials:
-        out.append("material %d %s %s %s %d %s %s" % (m.type, " ".join(_hx(v) for v in m.color), _hx(m.alpha),
-                                                     _hx(m.power), int(m.two_sided), _hx(m.fuzz), _hx(m.ior)))
+        out.append("material %d %s %s %s %d %s %s %d" % (m.type, " ".join(_hx(v) for v in m.color), _hx(m.alpha),
+                                                        _hx(m.power), int(m.two_sided), _hx(m.fuzz), _hx(m.ior), m.texture))
     for p in sp.prims:
         if p.type == PRIM_RECT:
             out.append("prim rect %d %s %d %d" % (p.mat, " ".join(_hx(v) for v in p.rect), p.plane, int(p.flipped)))

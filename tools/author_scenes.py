@@ -177,6 +177,101 @@ scenes["cornell_box_with_volume2"] = {
     + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
 }
 
+# The reference's seventh scene, cornell_box_image_light.json.  Its "png" texture points at
+# assets/light_texture.png, which the reference repository does not contain, so the reference cannot load the file as
+# shipped; here that one texture entry carries the parser's own "skip" flag (scene_parser.h:265).  Nothing else refers to
+# it (the keys spelled "texture2" are ignored by the parser), so the scene is otherwise the reference's: a checker
+# lambertian on a 10 km sphere under the floor, a metal sphere, constant textures referenced by id, an unused perlin one.
+def const_tex(tid, rgb, alpha=1.0):
+    return {"id": tid, "type": "constant", "data": {"color": list(rgb), "alpha": alpha}}
+
+
+scenes["cornell_box_image_light"] = {
+    "camera": cam((-100.0, 400.0, -750.0), (278.0, 278.0, 0.0), 70.0, 100.0),
+    "world": {"color": [0.0, 0.0, 0.0], "texture2": "checker_texture"},
+    "assets": [],
+    "textures": [
+        {"skip": True, "id": "light_texture", "type": "png", "data": {"path": "assets/light_texture.png"}},
+        const_tex("green", (0.12, 0.85, 0.05)), const_tex("red", (1.0, 0.05, 0.05)),
+        const_tex("transparent_red", (1.0, 0.05, 0.05), 0.5), const_tex("blue", (0.05, 0.05, 1.0)),
+        {"id": "checker_texture", "type": "checker", "data": {"scale": 0.05, "odd": {"texture": "red"}, "even": {"texture": "blue"}}},
+        {"id": "noise_texture", "type": "perlin", "data": {"scale": 0.1}},
+    ],
+    "materials": [
+        {"id": "green", "type": "lambertian", "data": {"texture": "green"}},
+        {"id": "red", "type": "lambertian", "data": {"texture": "red"}},
+        {"id": "white", "type": "lambertian", "data": {"texture2": "checker_texture", "color": [0.73, 0.73, 0.73]}},
+        {"id": "checker_light", "type": "diffuse_light", "data": {"texture": "checker_texture", "power": 5}},
+        {"id": "noise", "type": "lambertian", "data": {"texture": "noise_texture"}},
+        {"id": "glass", "type": "dielectric", "data": {"ior": 1.5}},
+        {"id": "metal", "type": "metal", "data": {"roughness": 0.5}},
+        {"id": "checker", "type": "lambertian", "data": {"texture": "checker_texture"}},
+        {"id": "light", "type": "diffuse_light", "data": {"color": [1, 1, 1], "texture2": "light_texture", "power": 1, "two_sided": True}},
+    ],
+    "primitives": [
+        {"id": "white_wall", "type": "rect", "material": {"id": "white"}, "size": [555, 555]},
+        {"id": "box", "type": "box", "material": {"id": "white"}, "size": [165, 165, 165]},
+        {"id": "sphere", "type": "sphere", "material": {"id": "metal"}, "radius": 67.5},
+        {"id": "big_sphere", "type": "sphere", "material": {"id": "checker"}, "radius": 10000.0},
+    ],
+    "instances": [
+        ref("white_wall", translate=[277.5, 0.0, 277.5], rotate=[0.0, 0.0, 0.0]),
+        ref("white_wall", rotate=[1.0, 0.0, 0.0], translate=[277.5, 555, 277.5]),
+        ref("white_wall", rotate=[1.5, 0, 0], translate=[277.5, 277.5, 555]),
+        direct({"type": "rect", "material": {"id": "green"}, "size": [555, 555], "align": "yz", "flip": True},
+               translate=[555, 277.5, 277.5]),
+        direct({"type": "rect", "material": {"id": "red"}, "size": [555, 555], "align": "yz"},
+               translate=[0, 277.5, 277.5], rotate=[0.0, 0.0, 0.0]),
+        ref("sphere", translate=[212.5, 82.5, 147.5], rotate=[0.0, -0.1, 0.0]),
+        ref("big_sphere", translate=[277.5, -10000.0, 277.5]),
+        direct({"type": "box", "material": {"id": "white"}, "size": [165, 330, 165]},
+               translate=[347.5, 165, 377.5], rotate=[0.0, 0.05, 0.0]),
+        direct({"type": "rect", "material": {"id": "light"}, "size": [240, 230]}, translate=[273, 520.0, 171], rotate=[1.0, 0, 0]),
+    ],
+}
+
+# Not a reference scene: a coverage scene of our own for the texture row, in the reference's schema and
+# rendered by the real reference for the fixtures like the others -- perlin-noise floor, checker wall whose children are
+# textures by id, a checker-textured emitter with a half-transparent child (alpha scales the emission, material.h:218), a
+# second plain light, and a checker sky as World::background seen through the missing right wall and ceiling
+# (integrator.h:325-336).
+scenes["textured_room"] = {
+    "camera": camera(-750.0),
+    "world": {"texture": "sky"},
+    "assets": [],
+    "textures": [
+        const_tex("white", (0.73, 0.73, 0.73)), const_tex("green", (0.12, 0.45, 0.15)),
+        const_tex("warm", (1.0, 0.55, 0.2)), const_tex("cool_half", (0.3, 0.5, 1.0), 0.5),
+        {"id": "tiles", "type": "checker", "data": {"scale": 0.04, "odd": {"texture": "white"}, "even": {"texture": "green"}}},
+        {"id": "lamp", "type": "checker", "data": {"scale": 0.09, "odd": {"texture": "warm"}, "even": {"texture": "cool_half"}}},
+        {"id": "marble", "type": "perlin", "data": {"scale": 0.03}},
+        {"id": "sky", "type": "checker", "data": {"scale": 4.0, "odd": {"color": [0.35, 0.45, 0.7]}, "even": {"color": [0.08, 0.08, 0.12]}}},
+        {"id": "nested", "type": "checker", "data": {"scale": 0.011, "odd": {"texture": "tiles"}, "even": {"texture": "marble"}}},
+    ],
+    "materials": [
+        lambertian("red", (0.65, 0.05, 0.05)),
+        {"id": "tiles", "type": "lambertian", "data": {"texture": "tiles"}},
+        {"id": "marble", "type": "lambertian", "data": {"texture": "marble"}},
+        {"id": "nested", "type": "lambertian", "data": {"texture": "nested"}},
+        {"id": "lamp", "type": "diffuse_light", "data": {"texture": "lamp", "power": 6}},
+        {"id": "light", "type": "diffuse_light", "data": {"color": [9.0, 9.0, 9.0], "two_sided": False}},
+    ],
+    "primitives": [
+        {"id": "floor", "type": "rect", "material": {"id": "marble"}, "size": [555, 555]},
+        {"id": "back", "type": "rect", "material": {"id": "tiles"}, "size": [555, 555]},
+    ],
+    "instances": [
+        ref("floor", translate=[277.5, 0.0, 277.5]),
+        ref("back", rotate=[1.5, 0, 0], translate=[277.5, 277.5, 555]),
+        direct({"type": "rect", "material": {"id": "red"}, "size": [555, 555], "align": "yz"}, translate=[0, 277.5, 277.5]),
+        direct({"type": "box", "material": {"id": "nested"}, "size": [165, 330, 165]},
+               translate=[347.5, 165, 377.5], rotate=[0.0, 0.05, 0.0]),
+        direct({"type": "sphere", "material": {"id": "tiles"}, "radius": 70}, translate=[190, 70, 190]),
+        direct({"type": "rect", "material": {"id": "lamp"}, "size": [260, 220]}, translate=[250, 500.0, 250], rotate=[1.0, 0, 0]),
+        direct({"type": "rect", "material": {"id": "light"}, "size": [60, 60], "flip": True}, translate=[420, 450.0, 120]),
+    ],
+}
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for name, sc in scenes.items():

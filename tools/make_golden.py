@@ -11,6 +11,8 @@ are data (inputs + expected outputs); no reference source is stored.
   F4  samples_<scene>.npy        first 4096 camera samples: u v ray(7) col(3) rays
   F5  hits_<scene>.npy           world->hit of the first 4096 camera rays: hit t p n inst
   F6  ppm_<scene>_64x64x4.ppm    the reference's P6 film output (tonemap + sRGB) for framebuffer fb_<scene>_64x64x4
+  F7  perlin_tables.npy          perlin::ranvec (768 floats) + perm_x/y/z (768 values) as the static initialisers left them
+  F8  texeval_<scene>.npz        2048 rows (u v px py pz) + every texture's value rgb / alpha there (texture scenes)
 """
 import json
 import os
@@ -28,6 +30,9 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
 # scenes beyond the BASELINE configs: sphere lights + metal, dielectric, a room-filling volume
 EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
+# checker / perlin textures, textured emitter, textured World::background (scenes/ + tools/author_scenes.py)
+TEXTURE_SCENES = ["cornell_box_image_light", "textured_room"]
+EXTRA_SCENES = EXTRA_SCENES + TEXTURE_SCENES
 
 # name -> (width, height, samples, kwargs)
 CONFIGS = {
@@ -48,20 +53,37 @@ def main():
     assert po.ref_available(), "oracle/_ref/ref_driver missing (needs /root/reference)"
     os.makedirs(GOLD, exist_ok=True)
     manifest = {"generator": "tools/make_golden.py", "reference_build": "g++ -pthread --std=c++14 -O3, threads=1",
-                "framebuffers": [], "samples": [], "hits": [], "tables": []}
+                "framebuffers": [], "samples": [], "hits": [], "tables": [], "texeval": []}
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "rng.f64")
         po.ref_run(sp.load_scene_params(os.path.join(ROOT, "scenes", SCENES[0] + ".json")), "rng", ["4096", out], d)
         np.save(os.path.join(GOLD, "rng_after_static_init.npy"), np.fromfile(out, np.float64))
+        out = os.path.join(d, "perlin.f32")
+        po.ref_run(sp.load_scene_params(os.path.join(ROOT, "scenes", SCENES[0] + ".json")), "perlin", [out], d)
+        np.save(os.path.join(GOLD, "perlin_tables.npy"), np.fromfile(out, np.float32))
         for scene in SCENES + EXTRA_SCENES:
             P = sp.load_scene_params(os.path.join(ROOT, "scenes", scene + ".json"))
+            if scene in TEXTURE_SCENES:
+                rng = np.random.default_rng(20260101)
+                n = 2048
+                pts = np.zeros((n, 5), np.float32)
+                pts[:, :2] = rng.uniform(-1.5, 2.5, (n, 2))
+                pts[: n // 2, 2:] = rng.uniform(-50, 600, (n // 2, 3))      # room-scale hit points
+                pts[n // 2:, 2:] = rng.normal(size=(n // 2, 3))            # unit directions (background lookups)
+                pts[n // 2:, 2:] /= np.linalg.norm(pts[n // 2:, 2:], axis=1, keepdims=True)
+                pin, pout = os.path.join(d, "pts.f32"), os.path.join(d, "tex.f32")
+                pts.tofile(pin)
+                po.ref_run(P, "texeval", [pin, str(n), pout], d)
+                vals = np.fromfile(pout, np.float32).reshape(len(P.textures), n, 4)
+                np.savez(os.path.join(GOLD, f"texeval_{scene}.npz"), points=pts, values=vals)
+                manifest["texeval"].append({"scene": scene, "file": f"texeval_{scene}.npz", "n": n, "textures": len(P.textures)})
             t = os.path.join(d, "tables.txt")
             po.ref_run(P, "tables", [t, "1920", "1080"], d)
             with open(t) as f, open(os.path.join(GOLD, f"tables_{scene}.txt"), "w") as g:
                 g.write(f.read())
             manifest["tables"].append({"scene": scene, "file": f"tables_{scene}.txt", "camera_aspect": [1920, 1080]})
             for cname, (w, h, spp, kw) in CONFIGS.items():
-                if scene in EXTRA_SCENES and cname not in ("64x64x4", "96x54x8_t32"):
+                if scene in EXTRA_SCENES and cname not in ("64x64x4", "96x54x8_t32") and not (scene in TEXTURE_SCENES and cname == "200x200x16"):
                     continue
                 if cname not in FULL_ONLY and cname != "64x64x4" and scene not in VARIANT_SCENES and scene not in EXTRA_SCENES:
                     continue
