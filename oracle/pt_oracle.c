@@ -163,6 +163,7 @@ float ptm_sinf(float x)
 /* atan2f / acosf for the environment-map coordinates of a missed ray (integrator.h:327-330); same rules as ptm_sinf */
 static double ptm_atan2_d(double y, double x)
 {
+    if (x != x || y != y) return x + y;
     const double ax = fabs(x), ay = fabs(y);
     const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
     double a = (mx > 0.0) ? mn / mx : 0.0;            /* [0, 1] */
@@ -180,7 +181,6 @@ static double ptm_atan2_d(double y, double x)
 }
 float ptm_atan2f(float y, float x)
 {
-    if (x != x || y != y) return x + y;
     return (float)ptm_atan2_d((double)y, (double)x);
 }
 float ptm_acosf(float x)
