@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
@@ -34,7 +34,21 @@ enum { PT_PLANE_XY = 0, PT_PLANE_XZ = 1, PT_PLANE_YZ = 2 };
 
 /* ---- flat POD scene: what World / bvh_node / instance / material objects hold at render time ---- */
 
-typedef struct pt_material {   /* material.h: lambertian / metal / diffuse_light / isotropic with constant_texture */
+/* texture.h: constant_texture :14-31, checker_texture :33-75, noise_texture :185-196; image.h:7-50 image_texture.
+ * A checker's children are indices of EARLIER entries of the table. */
+enum { PT_TEX_CONSTANT = 0, PT_TEX_CHECKER = 1, PT_TEX_PERLIN = 2, PT_TEX_IMAGE = 3 };
+typedef struct pt_texture {
+    int32_t type;
+    float color[3];            /* constant_texture::color */
+    float alpha;               /* constant_texture::a */
+    int32_t even, odd;         /* checker_texture::even / ::odd */
+    float scale;               /* checker_texture::scale, noise_texture::scale */
+    int32_t width, height;     /* image_texture */
+    int64_t texel_offset;      /* image_texture: byte offset of its RGBA8 pixels (what lodepng::decode returns, row 0
+                                  first; scene_parser.h:39-55) in pt_scene_desc::texels */
+} pt_texture;
+
+typedef struct pt_material {   /* material.h: lambertian / metal / diffuse_light / isotropic */
     int32_t type;
     float color[3];            /* albedo or emit colour (texture.h:14-31) */
     float alpha;               /* constant_texture::a */
@@ -42,6 +56,8 @@ typedef struct pt_material {   /* material.h: lambertian / metal / diffuse_light
     int32_t two_sided;         /* diffuse_light::two_sided */
     float fuzz, ior;           /* metal / dielectric: carried for completeness; neither influences NEEIterative's radiance
                                   (metal is cosine-diffuse material.h:99-108, a dielectric path ends after its NEE) */
+    int32_t texture;           /* lambertian / isotropic albedo, diffuse_light emit: index into pt_scene_desc::textures,
+                                  or -1 = the constant texture (color, alpha) above */
 } pt_material;
 
 typedef struct pt_primitive {
@@ -82,6 +98,12 @@ typedef struct pt_scene_desc {
     int32_t n_lights;     const int32_t *lights;          /* World::lights as instance indices (world.h:39) */
     pt_camera camera;
     float background[3];                                  /* World::background, constant colour (world.h:27-30) */
+    /* textures; all optional: n_textures = 0, background_texture = -1 */
+    int32_t n_textures;   const pt_texture *textures;
+    int64_t texel_bytes;  const uint8_t *texels;          /* RGBA8 pixels of the image textures */
+    int32_t background_texture;                           /* World::background as a texture index, -1 = the colour above */
+    const float *perlin_ranvec;                           /* perlin::ranvec, 256 x 3 (texture.h:176); required iff a perlin */
+    const int32_t *perlin_perm;                           /* perm_x, perm_y, perm_z, 3 x 256 (texture.h:177-179)  texture exists */
 } pt_scene_desc;
 
 typedef struct pt_config {     /* the Config fields the path reads (config.h:74-96) */

@@ -27,7 +27,13 @@ class PathtraceError(RuntimeError):
 
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("alpha", C.c_float), ("power", C.c_float),
-                ("two_sided", C.c_int32), ("fuzz", C.c_float), ("ior", C.c_float)]
+                ("two_sided", C.c_int32), ("fuzz", C.c_float), ("ior", C.c_float), ("texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("alpha", C.c_float), ("even", C.c_int32),
+                ("odd", C.c_int32), ("scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("texel_offset", C.c_int64)]
 
 
 class Primitive(C.Structure):
@@ -55,7 +61,11 @@ class SceneDesc(C.Structure):
                 ("n_instances", C.c_int32), ("instances", C.POINTER(Instance)),
                 ("n_nodes", C.c_int32), ("nodes", C.POINTER(BvhNode)),
                 ("n_lights", C.c_int32), ("lights", C.POINTER(C.c_int32)),
-                ("camera", Camera), ("background", C.c_float * 3)]
+                ("camera", Camera), ("background", C.c_float * 3),
+                ("n_textures", C.c_int32), ("textures", C.POINTER(Texture)),
+                ("texel_bytes", C.c_int64), ("texels", C.POINTER(C.c_uint8)),
+                ("background_texture", C.c_int32),
+                ("perlin_ranvec", C.POINTER(C.c_float)), ("perlin_perm", C.POINTER(C.c_int32))]
 
 
 class Config(C.Structure):
@@ -203,6 +213,19 @@ class Scene:
     def lights(self):
         d = self.desc
         return [d.lights[i] for i in range(d.n_lights)]
+
+    def textures(self):
+        d = self.desc
+        return [d.textures[i] for i in range(d.n_textures)]
+
+    def perlin_tables(self):
+        d = self.desc
+        return (np.array([d.perlin_ranvec[i] for i in range(768)], np.float32).reshape(256, 3),
+                np.array([d.perlin_perm[i] for i in range(768)], np.int32).reshape(3, 256))
+
+    def texel_bytes(self) -> bytes:
+        d = self.desc
+        return bytes(bytearray(d.texels[i] for i in range(d.texel_bytes)))
 
     def camera(self):
         c = self.desc.camera

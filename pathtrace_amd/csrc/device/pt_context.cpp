@@ -223,8 +223,56 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         DMat d{};
         d.type = m.type; d.r = m.color[0]; d.g = m.color[1]; d.b = m.color[2];
         d.alpha = m.alpha; d.power = m.power; d.two_sided = m.two_sided;
+        d.tex = -1;
+        if (m.texture >= 0) {
+            if (m.texture >= sc->n_textures) { set_err("pt_create: material %d: bad texture index %d", i, m.texture); return -1; }
+            // metal's albedo is a plain colour and a dielectric has none (material.h:79, 113-117)
+            if (m.type == PT_MAT_LAMBERTIAN || m.type == PT_MAT_DIFFUSE_LIGHT || m.type == PT_MAT_ISOTROPIC) d.tex = m.texture;
+        }
         mats[i] = d;
     }
+    // ---- textures (texture.h, image.h) ----
+    std::vector<DTex> texs((size_t)std::max(sc->n_textures, 0));
+    std::vector<float4> texels;
+    bool any_perlin = false;
+    for (int i = 0; i < sc->n_textures; i++) {
+        const pt_texture &t = sc->textures[i];
+        DTex d{};
+        d.type = t.type; d.even = t.even; d.odd = t.odd; d.scale = t.scale;
+        d.r = t.color[0]; d.g = t.color[1]; d.b = t.color[2]; d.a = t.alpha;
+        switch (t.type) {
+        case PT_TEX_CONSTANT: break;
+        case PT_TEX_CHECKER:
+            if (t.even < 0 || t.even >= i || t.odd < 0 || t.odd >= i) {
+                set_err("pt_create: texture %d: checker children must be earlier entries of the table", i);
+                return -1;
+            }
+            d.uses_uv = texs[t.even].uses_uv | texs[t.odd].uses_uv;
+            break;
+        case PT_TEX_PERLIN: any_perlin = true; break;
+        case PT_TEX_IMAGE: {
+            const int64_t n = (int64_t)t.width * t.height;
+            if (t.width < 1 || t.height < 1 || t.texel_offset < 0 || !sc->texels || t.texel_offset + 4 * n > sc->texel_bytes ||
+                (int64_t)texels.size() + n > INT32_MAX) {
+                set_err("pt_create: texture %d: bad image extent", i);
+                return -1;
+            }
+            d.width = t.width; d.height = t.height; d.texel0 = (int32_t)texels.size(); d.uses_uv = 1;
+            const uint8_t *px = sc->texels + t.texel_offset;
+            for (int64_t k = 0; k < n; k++)   // from_4byte_vector image.h:52-69: byte / 255.0 in double, stored as float
+                texels.push_back(make_float4((float)(px[4 * k] / 255.0), (float)(px[4 * k + 1] / 255.0),
+                                             (float)(px[4 * k + 2] / 255.0), (float)(px[4 * k + 3] / 255.0)));
+            break;
+        }
+        default: set_err("pt_create: texture %d: bad type %d", i, t.type); return -1;
+        }
+        texs[i] = d;
+    }
+    if (any_perlin && (!sc->perlin_ranvec || !sc->perlin_perm)) {
+        set_err("pt_create: a perlin texture needs pt_scene_desc::perlin_ranvec / perlin_perm");
+        return -1;
+    }
+    if (sc->background_texture >= sc->n_textures) { set_err("pt_create: bad background_texture %d", sc->background_texture); return -1; }
     std::vector<DPrim> prims(sc->n_primitives);
     for (int i = 0; i < sc->n_primitives; i++) {
         const pt_primitive &p = sc->primitives[i];
@@ -259,6 +307,14 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         default: set_err("pt_create: primitive %d: unsupported type %d", i, p.type); return -1;
         }
         for (int f = 0; f < 8; f++) d.hit_mat[f] = (p.type == PT_PRIM_VOLUME) ? p.phase_material : p.material;
+        {   // sphere::hit and constant_medium::hit leave rec.u / rec.v unset (primitive.h:63-102, volume.h:29-93): an
+            // image texture there reads indeterminate values in the reference
+            const DMat &hm = mats[d.hit_mat[0]];
+            if (hm.tex >= 0 && texs[hm.tex].uses_uv && p.type != PT_PRIM_RECT && p.type != PT_PRIM_BOX) {
+                set_err("pt_create: primitive %d: an image texture needs the u, v of a rect / box hit", i);
+                return -1;
+            }
+        }
         prims[i] = d;
     }
     std::vector<DInst> insts(sc->n_instances);
@@ -318,10 +374,27 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             const DMat &m = mats[prims[insts[i].prim].hit_mat[f]];
             if (m.type != PT_MAT_DIFFUSE_LIGHT) continue;
             const float pr = m.power * m.r, pg = m.power * m.g, pb = m.power * m.b;
-            emit[(size_t)i * 8 + f] = make_float4(m.alpha * pr, m.alpha * pg, m.alpha * pb, m.two_sided ? 0.f : 1.f);
+            emit[(size_t)i * 8 + f] = make_float4(m.alpha * pr, m.alpha * pg, m.alpha * pb,
+                                                  (m.two_sided ? 0.f : 1.f) + (m.tex >= 0 ? 2.f : 0.f));
         }
+    std::vector<float4> ranvec(256, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<int32_t> perm(768, 0);
+    if (sc->perlin_ranvec && sc->perlin_perm) {
+        for (int i = 0; i < 256; i++) ranvec[i] = make_float4(sc->perlin_ranvec[3 * i], sc->perlin_ranvec[3 * i + 1], sc->perlin_ranvec[3 * i + 2], 0.f);
+        for (int i = 0; i < 768; i++) {
+            if (sc->perlin_perm[i] < 0 || sc->perlin_perm[i] > 255) { set_err("pt_create: perlin_perm[%d] out of range", i); return -1; }
+            perm[i] = sc->perlin_perm[i];
+        }
+    }
+    if (texs.empty()) texs.push_back(DTex{});
+    if (texels.empty()) texels.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     DScene &S = c->S;
     if (dev_upload(c, &S.emit, emit)) return -1;
+    if (dev_upload(c, &S.tex, texs) || dev_upload(c, &S.texels, texels) || dev_upload(c, &S.ranvec, ranvec) || dev_upload(c, &S.perm, perm))
+        return -1;
+    S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
+    S.textured = S.bg_tex >= 0;
+    for (const DMat &m : mats) S.textured |= m.tex >= 0;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
         dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
         return -1;

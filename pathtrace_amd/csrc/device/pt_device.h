@@ -37,7 +37,16 @@ struct DMat {            // 32 bytes
     float r, g, b;
     float alpha, power;
     int32_t two_sided;
-    int32_t pad;
+    int32_t tex;         // albedo / emit texture (DScene::tex index) when it is not a constant one, else -1
+};
+// texture.h / image.h.  Read with per-lane indices (which child a checker picks depends on the hit point).
+struct DTex {            // 48 bytes
+    int32_t type;        // PT_TEX_*
+    int32_t even, odd;   // checker children
+    float scale;         // checker, perlin
+    float r, g, b, a;    // constant
+    int32_t width, height, texel0;   // image: texels[texel0 + y*width + x]
+    int32_t uses_uv;     // the tree below reaches an image texture (hit_record u, v are needed)
 };
 // Traversal program: the pointer BVH (reference bvh.h:31-69) flattened into a linear op list that every
 // lane of a wave sweeps in lock step.  eval(node) = ENTER box-test (miss: result MISS, jump to `a`) ;
@@ -79,8 +88,15 @@ struct DScene {
     const DMat *mats;
     const DOp *ops;
     const int32_t *lights;
-    const float4 *emit;          // [n_insts*8] by hit id: emitted radiance of that face's material (xyz), w = 1 if it
-                                 // is a one-sided diffuse_light (needs the facing test of material.h:214-216), else 0
+    const float4 *emit;          // [n_insts*8] by hit id: emitted radiance of that face's material (xyz); w = 0: that is
+                                 // all; w bit 0: one-sided diffuse_light (facing test of material.h:214-216), bit 1:
+                                 // textured emit (value/alpha at the hit point) -- both need the hit record
+    const DTex *tex;             // texture table, texels as float4 (byte / 255.0 like image.h:58-62)
+    const float4 *texels;
+    const float4 *ranvec;        // perlin::ranvec[256] (xyz), perlin perm_x / perm_y / perm_z [3][256]
+    const int32_t *perm;
+    int32_t bg_tex;              // World::background texture, -1 = the constant bg[] below
+    int32_t textured;            // some material or the background uses the texture table: launch the <TEX = true> kernels
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
     int32_t stack_depth;         // short-stack slots the program uses
     DCamera cam;

@@ -120,6 +120,52 @@ DEVI float ptm_logf(float x)
     return fe * 0.693145752f + (fe * 1.42860677e-06f + p);
 }
 
+// sinf / atan2f / acosf of the texture row (checker_texture::sines texture.h:70-73, environment coordinates
+// integrator.h:327-330): double +,-,*,/ and rint in a fixed order, the same statements as oracle/pt_oracle.c
+DEVI double ptm_sin_reduced(double r, int q)
+{
+    const double r2 = r * r;
+    const double sp = r + r * r2 * (-1.6666666666666666e-01 + r2 * (8.3333333333333332e-03 + r2 * (-1.9841269841269841e-04
+                      + r2 * (2.7557319223985893e-06 + r2 * (-2.5052108385441720e-08 + r2 * 1.6059043836821613e-10)))));
+    const double cp = 1.0 + r2 * (-0.5 + r2 * (4.1666666666666664e-02 + r2 * (-1.3888888888888889e-03 + r2 * (2.4801587301587302e-05
+                      + r2 * (-2.7557319223985888e-07 + r2 * (2.0876756987868100e-09 + r2 * -1.1470745597729725e-11))))));
+    return (q & 1) ? ((q & 2) ? -cp : cp) : ((q & 2) ? -sp : sp);
+}
+DEVI float ptm_sinf(float x)
+{
+    if (!(fabsf(x) < 1073741824.0f)) return x - x;
+    const double xd = (double)x;
+    const double k = rint(xd * 0.63661977236758138);
+    const double r = ((xd - k * 1.5707963267341256) - k * 6.077100506303966e-11) - k * 2.0222662487959506e-21;
+    return (float)ptm_sin_reduced(r, (int)k & 3);
+}
+DEVI double ptm_atan2_d(double y, double x)
+{
+    if (x != x || y != y) return x + y;
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    double a = (mx > 0.0) ? mn / mx : 0.0;
+    double off = 0.0;
+    if (a > 0.41421356237309503) { a = (a - 1.0) / (a + 1.0); off = 0.78539816339744828; }
+    const double z = a * a;
+    double p = 1.0 / 27.0;
+    p = 1.0 / 25.0 - z * p; p = 1.0 / 23.0 - z * p; p = 1.0 / 21.0 - z * p; p = 1.0 / 19.0 - z * p; p = 1.0 / 17.0 - z * p;
+    p = 1.0 / 15.0 - z * p; p = 1.0 / 13.0 - z * p; p = 1.0 / 11.0 - z * p; p = 1.0 / 9.0 - z * p; p = 1.0 / 7.0 - z * p;
+    p = 1.0 / 5.0 - z * p; p = 1.0 / 3.0 - z * p; p = 1.0 - z * p;
+    double t = off + a * p;
+    if (ay > ax) t = 1.5707963267948966 - t;
+    if (x < 0.0) t = 3.1415926535897931 - t;
+    return (y < 0.0) ? -t : t;
+}
+DEVI float ptm_atan2f(float y, float x) { return (float)ptm_atan2_d((double)y, (double)x); }
+DEVI float ptm_acosf(float x)
+{
+    const double xd = (double)x;
+    return (float)ptm_atan2_d(sqrt((1.0 - xd) * (1.0 + xd)), xd);
+}
+// float -> int as the reference's x86 build converts (cvttss2si): truncation, INT_MIN for NaN and out-of-range values
+DEVI int f2i_x86(float f) { return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000; }
+
 // stream-mode dimension layout (must match oracle/pt_oracle.c "stream-mode dimension layout")
 #define DIM_JITTER_U 0u
 #define DIM_JITTER_V 1u
@@ -423,8 +469,86 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// textures (texture.h, image.h): per-lane table reads, off the fast path of the constant-texture scenes
+// ------------------------------------------------------------------------------------------------
+// perlin::noise texture.h:134-160 + perlin_interp :111-131 (the Hermite smoothing is applied twice, as written there)
+DEVI float perlin_noise(const DScene &S, v3 p)
+{
+    float u = p.x - floorf(p.x);
+    float v = p.y - floorf(p.y);
+    float w = p.z - floorf(p.z);
+    u = u * u * (3 - 2 * u);
+    v = v * v * (3 - 2 * v);
+    w = w * w * (3 - 2 * w);
+    const int i = f2i_x86(floorf(p.x));
+    const int j = f2i_x86(floorf(p.y));
+    const int k = f2i_x86(floorf(p.z));
+    const float uu = u * u * (3 - 2 * u);
+    const float vv = v * v * (3 - 2 * v);
+    const float ww = w * w * (3 - 2 * w);
+    float accum = 0;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                const float4 c4 = S.ranvec[S.perm[(i + di) & 255] ^ S.perm[256 + ((j + dj) & 255)] ^ S.perm[512 + ((k + dk) & 255)]];
+                const v3 weight_v = V(u - di, v - dj, w - dk);
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) *
+                         vdot(V(c4.x, c4.y, c4.z), weight_v);
+            }
+    return accum;
+}
+// texture::value(u, v, p) and ::alpha(u, v, p); a checker picks the same child for both (texture.h:43-68)
+DEVI void tex_eval(const DScene &S, int ti, float u, float v, v3 p, v3 &color, float &alpha)
+{
+    for (;;) {
+        const DTex t = S.tex[ti];
+        if (t.type == 1) {   // PT_TEX_CHECKER
+            const float sx = ptm_sinf(t.scale * p.x), sy = ptm_sinf(t.scale * p.y), sz = ptm_sinf(t.scale * p.z);
+            ti = (sx * sy * sz > 0) ? t.odd : t.even;
+            continue;
+        }
+        if (t.type == 2) {   // PT_TEX_PERLIN: noise_texture::value texture.h:190-193 = vec3(1,1,1) * noise; alpha(): 1.0
+            const float n = perlin_noise(S, vscale(t.scale, p));
+            color = V(n, n, n);
+            alpha = 1.0f;
+            return;
+        }
+        if (t.type == 3) {   // PT_TEX_IMAGE: image.h:15-49
+            v -= f2i_x86(v);
+            if (v < 0) v += 1;
+            u -= f2i_x86(u);
+            if (u < 0) u += 1;
+            int y = f2i_x86(v * t.height);
+            int x = f2i_x86(u * t.width);
+            if (y > t.height - 1) y = t.height - 1;   // u or v == 1.0f after the wrap: the reference reads out of bounds
+            if (x > t.width - 1) x = t.width - 1;
+            if (y < 0) y = 0;                          // NaN coordinates
+            if (x < 0) x = 0;
+            const float4 px = S.texels[t.texel0 + y * t.width + x];
+            color = V(px.x, px.y, px.z);
+            alpha = px.w;
+            return;
+        }
+        color = V(t.r, t.g, t.b);
+        alpha = t.a;
+        return;
+    }
+}
+
 // hit_record of the winning primitive: rec.p, rec.normal, rec.mat_ptr  (primitive.h:186-225, 298-312; volume.h:77-88)
-struct HitInfo { v3 p, n; int mat; };
+struct HitInfo { v3 p, n; int mat; v3 pl; };
+// rec.u, rec.v of a rect / box-face hit (primitive.h:206-207; v divides (zh - x0), sic), from the local hit point
+DEVI void rect_uv(const DScene &S, int id, v3 pl, float &u, float &v)
+{
+    const DPrim &pr = S.prims[S.insts[id >> 3].prim];
+    u = 0.0f; v = 0.0f;
+    if (pr.type > 1) return;
+    const DRect &q = pr.r[id & 7];
+    const v3 h = shuffle(pl, q.plane);   // pl = o + t*d computed per component, exactly the xh / zh of rect::hit
+    u = (h.x - q.x0) / (q.x1 - q.x0);
+    v = (h.z - q.x0) / (q.z1 - q.z0);
+}
 DEVI HitInfo finalize_hit(const DScene &S, v3 A, v3 B, float t, int id, bool need_normal)
 {
     const int ii = id >> 3, face = id & 7;
@@ -445,6 +569,7 @@ DEVI HitInfo finalize_hit(const DScene &S, v3 A, v3 B, float t, int id, bool nee
     else nl = V(1.0f, 0.0f, 0.0f);
     h.p = xf_point(in.fwd, pl);
     h.n = need_normal ? xf_normal(in.inv, nl) : V(0.0f, 0.0f, 0.0f);
+    h.pl = pl;
     return h;
 }
 
@@ -578,11 +703,31 @@ DEVI v3 material_generate(int type, v3 normal, uint32_t k0, uint32_t k1, uint32_
     if (type == 2) return V(0.0f, 0.0f, 0.0f);
     return random_in_unit_sphere(k0, k1, dim);
 }
-DEVI v3 material_emitted(const DMat &m, v3 ray_dir, v3 normal)
+// albedo->value / emit->value and ->alpha at the hit (rec.u, rec.v, rec.p): the material's own constant texture, or
+// its entry of the texture table
+DEVI void material_texture(const DScene &S, const DMat &m, int id, const HitInfo &hi, v3 &color, float &alpha)
+{
+    color = V(m.r, m.g, m.b);
+    alpha = m.alpha;
+    if (m.tex >= 0) {
+        float u = 0.0f, v = 0.0f;
+        if (S.tex[m.tex].uses_uv) rect_uv(S, id, hi.pl, u, v);
+        tex_eval(S, m.tex, u, v, hi.p, color, alpha);
+    }
+}
+// TEX = false: the scene has no texture table entries in use (every BASELINE scene); the texture code is compiled out
+// so that it costs those kernels neither registers nor occupancy
+template <bool TEX>
+DEVI v3 material_emitted(const DScene &S, const DMat &m, int id, const HitInfo &hi, v3 ray_dir)
 {   // material.h:211-229 (others: material.h:21-24)
     if (m.type != 3) return V(0.0f, 0.0f, 0.0f);
-    bool aligned = vdot(normal, ray_dir) > 0;
-    if (!aligned || m.two_sided) return vscale(m.alpha, vscale(m.power, V(m.r, m.g, m.b)));
+    bool aligned = vdot(hi.n, ray_dir) > 0;
+    if (!aligned || m.two_sided) {
+        v3 c = V(m.r, m.g, m.b);
+        float a = m.alpha;
+        if (TEX) material_texture(S, m, id, hi, c, a);
+        return vscale(a, vscale(m.power, c));
+    }
     return V(0.0f, 0.0f, 0.0f);
 }
 
@@ -749,6 +894,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
 // material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
 // continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
 // ------------------------------------------------------------------------------------------------
+template <bool TEX>
 __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -820,15 +966,17 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                 // scatter(): material.h:39-53 lambertian, :90-98 metal, :187-191 diffuse_light (attenuation keeps
                 // its previous value), :252-261 isotropic
                 bool did_scatter = true;
+                v3 albedo = V(m.r, m.g, m.b);
+                if (TEX && m.tex >= 0 && m.type != 3) { float ta; material_texture(S, m, id, hi, albedo, ta); }   // albedo->value(rec.u, rec.v, rec.p)
                 if (m.type == 0) {
-                    if (vdot(B, hi.n) < 0) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
+                    if (vdot(B, hi.n) < 0) att = vdivf(albedo, PT_PI_F);
                     else att = V(0.0f, 0.0f, 0.0f);
                 } else if (m.type == 1) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
                 else if (m.type == 2) att = V(1.0f, 1.0f, 1.0f);   // dielectric::scatter material.h:118-124
                 else if (m.type == 3) did_scatter = false;
-                else if (m.type == 4) att = V(m.r, m.g, m.b);
+                else if (m.type == 4) att = albedo;
                 const float cos_i = fabsf(vdot(vunit(B), vunit(hi.n)));
-                const v3 hit_emission = material_emitted(m, B, hi.n);
+                const v3 hit_emission = material_emitted<TEX>(S, m, id, hi, B);
                 if ((double)vsqlen(hit_emission) > 0.000001) {   // integrator.h:205-218
                     v3 add;
                     if (last_bsdf_pdf <= 0) add = vmul(beta, hit_emission);
@@ -944,14 +1092,15 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
 // ------------------------------------------------------------------------------------------------
 // emitted() of whatever a shadow ray hit, times the stored coefficient (integrator.h:252-262).  The emitted radiance
 // comes from one table load by hit id; non-emitters contribute (coef*0)/pick = +-0 or NaN, i.e. nothing.
+template <bool TEX>
 DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id, v3 coef, float pick_pdf, v3 &lc)
 {
     if (id < 0) return;
     const float4 e = S.emit[id];
     v3 le = V(e.x, e.y, e.z);
-    if (e.w != 0.0f) {   // one-sided light: material.h:214-228
+    if (e.w != 0.0f) {   // one-sided and / or textured light: needs the hit record (material.h:214-228)
         const DMat m = S.mats[S.prims[S.insts[id >> 3].prim].hit_mat[id & 7]];
-        le = material_emitted(m, ldir, finalize_hit(S, hp, ldir, t, id, true).n);
+        le = material_emitted<TEX>(S, m, id, finalize_hit(S, hp, ldir, t, id, true), ldir);
     }
     if (le.x == 0.0f && le.y == 0.0f && le.z == 0.0f) return;
     v3 c = vmul(coef, le);
@@ -960,7 +1109,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 }
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
-template <int NR>
+template <int NR, bool TEX>
 __global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
@@ -1013,7 +1162,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__
                 world_hit_n<R>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
                 if (valid) {
 #pragma unroll
-                    for (int k = 0; k < R; k++) connect_contribution(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
+                    for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
                 }
             }
         } else {
@@ -1025,7 +1174,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__
                 float t[1];
                 int id[1];
                 world_hit_n<1>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
-                if (valid) connect_contribution(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
+                if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
         if (valid) {
@@ -1114,7 +1263,8 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_shade, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    if (S.textured) hipLaunchKernelGGL(k_shade<true>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
@@ -1125,10 +1275,19 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     int nr = (L % 2 == 0) ? 2 : 1;
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
-    if (nr == 4) hipLaunchKernelGGL(k_connect<4>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else if (nr == 2) hipLaunchKernelGGL(k_connect<2>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else if (nr == 1) hipLaunchKernelGGL(k_connect<1>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
-    else hipLaunchKernelGGL(k_connect<0>, dim3(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce);
+    const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
+#define PT_LAUNCH_CONNECT(NR, TEX) hipLaunchKernelGGL((k_connect<NR, TEX>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
+    if (S.textured) {   // k_connect<0> (wave-per-hit variant) is not instantiated with textures: one ray per lane instead
+        if (nr == 4) PT_LAUNCH_CONNECT(4, true);
+        else if (nr == 2) PT_LAUNCH_CONNECT(2, true);
+        else PT_LAUNCH_CONNECT(1, true);
+    } else {
+        if (nr == 4) PT_LAUNCH_CONNECT(4, false);
+        else if (nr == 2) PT_LAUNCH_CONNECT(2, false);
+        else if (nr == 1) PT_LAUNCH_CONNECT(1, false);
+        else PT_LAUNCH_CONNECT(0, false);
+    }
+#undef PT_LAUNCH_CONNECT
 }
 void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s)

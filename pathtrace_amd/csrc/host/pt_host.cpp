@@ -71,7 +71,7 @@ struct Mt19937 {
         return r;
     }
 };
-const int PERLIN_STATIC_DRAWS = 1533;   // texture.h:180-183 consume 256*3 + 3*255 values before main()
+// texture.h:180-183: the static initialisers consume 256*3 + 3*255 = 1533 values before main() (SceneBuilder::build)
 
 // ---- transform3 (transform3.h:19-68) through the Eigen 3.2.10 code paths it instantiates
 struct Quat { float x, y, z, w; };
@@ -148,6 +148,188 @@ Box rect_bbox(float x0, float z0, float x1, float z1, float y, int plane)
     return Box{shuffle(v3(x0, (float)(y - 0.001), z0), plane), shuffle(v3(x1, (float)(y + 0.001), z1), plane)};
 }
 
+// ---- PNG -> RGBA8, i.e. what lodepng::decode(image, w, h, path) hands to from_4byte_vector (scene_parser.h:39-55).
+// lodepng is an un-vendored submodule of the reference (thirdparty/lodepng, .gitmodules); this is a plain reader of
+// the published formats (RFC 1950/1951 inflate, PNG filters) for non-interlaced 8-bit images of all five colour types.
+struct BitReader {
+    const uint8_t *p; size_t n, pos = 0; uint32_t acc = 0; int cnt = 0;
+    BitReader(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    uint32_t bits(int k)
+    {
+        while (cnt < k) {
+            if (pos >= n) throw pth::JsonError("PNG: truncated deflate stream");
+            acc |= (uint32_t)p[pos++] << cnt; cnt += 8;
+        }
+        uint32_t v = acc & ((1u << k) - 1u);
+        acc >>= k; cnt -= k;
+        return v;
+    }
+    void align() { acc = 0; cnt = 0; }
+};
+struct Huffman {
+    uint16_t count[16] = {0}, symbol[320] = {0};
+    void build(const uint8_t *len, int n)
+    {
+        memset(count, 0, sizeof count);
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        uint16_t offs[16]; offs[1] = 0;
+        for (int i = 1; i < 15; i++) offs[i + 1] = offs[i] + count[i];
+        for (int i = 0; i < n; i++) if (len[i]) symbol[offs[len[i]]++] = (uint16_t)i;
+    }
+    int decode(BitReader &br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len <= 15; len++) {
+            code |= (int)br.bits(1);
+            int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        throw pth::JsonError("PNG: bad Huffman code");
+    }
+};
+std::vector<uint8_t> inflate_zlib(const std::vector<uint8_t> &z)
+{
+    if (z.size() < 6 || (z[0] & 15) != 8) throw pth::JsonError("PNG: not a zlib stream");
+    BitReader br(z.data() + 2, z.size() - 2);
+    std::vector<uint8_t> out;
+    static const int lbase[] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+    static const int lext[] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+    static const int dbase[] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+    static const int dext[] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+    for (bool last = false; !last;) {
+        last = br.bits(1);
+        const int type = (int)br.bits(2);
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) throw pth::JsonError("PNG: truncated stored block");
+            size_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > br.n) throw pth::JsonError("PNG: truncated stored block");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) throw pth::JsonError("PNG: bad deflate block type");
+        Huffman lit, dist;
+        uint8_t lens[320];
+        if (type == 1) {
+            for (int i = 0; i < 288; i++) lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+            lit.build(lens, 288);
+            for (int i = 0; i < 30; i++) lens[i] = 5;
+            dist.build(lens, 30);
+        } else {
+            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            static const int order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+            Huffman lc;
+            lc.build(cl, 19);
+            int i = 0;
+            while (i < nlen + ndist) {
+                int sym = lc.decode(br);
+                if (sym < 16) lens[i++] = (uint8_t)sym;
+                else {
+                    int rep, val = 0;
+                    if (sym == 16) { if (!i) throw pth::JsonError("PNG: bad code lengths"); val = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+                    else if (sym == 17) rep = 3 + (int)br.bits(3);
+                    else rep = 11 + (int)br.bits(7);
+                    if (i + rep > nlen + ndist) throw pth::JsonError("PNG: bad code lengths");
+                    while (rep--) lens[i++] = (uint8_t)val;
+                }
+            }
+            lit.build(lens, nlen);
+            dist.build(lens + nlen, ndist);
+        }
+        for (;;) {
+            int sym = lit.decode(br);
+            if (sym < 256) out.push_back((uint8_t)sym);
+            else if (sym == 256) break;
+            else {
+                sym -= 257;
+                if (sym >= 29) throw pth::JsonError("PNG: bad length symbol");
+                int len = lbase[sym] + (int)br.bits(lext[sym]);
+                int ds = dist.decode(br);
+                if (ds >= 30) throw pth::JsonError("PNG: bad distance symbol");
+                size_t d = (size_t)dbase[ds] + br.bits(dext[ds]);
+                if (d > out.size()) throw pth::JsonError("PNG: distance too far back");
+                for (int k = 0; k < len; k++) out.push_back(out[out.size() - d]);
+            }
+        }
+    }
+    return out;
+}
+std::string read_file(const std::string &path);
+std::vector<uint8_t> decode_png(const std::string &path, int &width, int &height)
+{
+    const std::string raw = read_file(path);
+    const uint8_t *b = (const uint8_t *)raw.data();
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (raw.size() < 8 || memcmp(b, sig, 8)) throw pth::JsonError("not a PNG file: " + path);
+    auto be32 = [&](size_t o) { return ((uint32_t)b[o] << 24) | (b[o + 1] << 16) | (b[o + 2] << 8) | b[o + 3]; };
+    std::vector<uint8_t> idat, plte, trns;
+    int depth = 0, ctype = 0, interlace = 0;
+    bool have_hdr = false;
+    for (size_t pos = 8; pos + 12 <= raw.size();) {
+        const uint32_t n = be32(pos);
+        const std::string typ(raw, pos + 4, 4);
+        if (pos + 12 + n > raw.size()) throw pth::JsonError("PNG: truncated chunk in " + path);
+        const uint8_t *body = b + pos + 8;
+        if (typ == "IHDR" && n >= 13) {
+            width = (int)be32(pos + 8); height = (int)be32(pos + 12);
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+            have_hdr = true;
+        } else if (typ == "PLTE") plte.assign(body, body + n);
+        else if (typ == "tRNS") trns.assign(body, body + n);
+        else if (typ == "IDAT") idat.insert(idat.end(), body, body + n);
+        else if (typ == "IEND") break;
+        pos += 12 + n;
+    }
+    if (!have_hdr || width < 1 || height < 1) throw pth::JsonError("PNG: no IHDR in " + path);
+    if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6))
+        throw pth::JsonError("PNG: only non-interlaced 8-bit images are supported (" + path + ")");
+    const int ch = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 3 ? 1 : (ctype == 4 ? 2 : 4)));
+    const size_t stride = (size_t)width * ch;
+    std::vector<uint8_t> data = inflate_zlib(idat);
+    if (data.size() < (stride + 1) * (size_t)height) throw pth::JsonError("PNG: image data too short in " + path);
+    std::vector<uint8_t> px(stride * height), prev(stride, 0);
+    for (int y = 0; y < height; y++) {
+        const uint8_t ft = data[(stride + 1) * y];
+        const uint8_t *line = &data[(stride + 1) * y + 1];
+        uint8_t *cur = &px[stride * y];
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)ch ? cur[i - ch] : 0, bb = prev[i], c = i >= (size_t)ch ? prev[i - ch] : 0;
+            int pr = 0;
+            if (ft == 1) pr = a;
+            else if (ft == 2) pr = bb;
+            else if (ft == 3) pr = (a + bb) >> 1;
+            else if (ft == 4) {
+                const int pa = std::abs(bb - c), pb = std::abs(a - c), pc = std::abs(a + bb - 2 * c);
+                pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c);
+            } else if (ft != 0) throw pth::JsonError("PNG: bad filter type in " + path);
+            cur[i] = (uint8_t)(line[i] + pr);
+        }
+        memcpy(prev.data(), cur, stride);
+    }
+    std::vector<uint8_t> out((size_t)width * height * 4);
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        uint8_t r, g, bl, a = 255;
+        const uint8_t *q = &px[i * ch];
+        if (ctype == 0) { r = g = bl = q[0]; if (trns.size() >= 2 && q[0] == trns[1]) a = 0; }
+        else if (ctype == 4) { r = g = bl = q[0]; a = q[1]; }
+        else if (ctype == 2) { r = q[0]; g = q[1]; bl = q[2]; if (trns.size() >= 6 && r == trns[1] && g == trns[3] && bl == trns[5]) a = 0; }
+        else if (ctype == 6) { r = q[0]; g = q[1]; bl = q[2]; a = q[3]; }
+        else {
+            if ((size_t)q[0] * 3 + 2 >= plte.size()) throw pth::JsonError("PNG: palette index out of range in " + path);
+            r = plte[q[0] * 3]; g = plte[q[0] * 3 + 1]; bl = plte[q[0] * 3 + 2];
+            if (q[0] < trns.size()) a = trns[q[0]];
+        }
+        out[4 * i] = r; out[4 * i + 1] = g; out[4 * i + 2] = bl; out[4 * i + 3] = a;
+    }
+    return out;
+}
+
 struct WrappedMaterial { int index; std::string type; };   // scene_parser.h:57-69
 struct WrappedPrim { int index; WrappedMaterial mat; };    // scene_parser.h:73-89
 
@@ -159,6 +341,10 @@ struct pth_scene {
     std::vector<pt_instance> instances;
     std::vector<pt_bvh_node> nodes;
     std::vector<int32_t> lights;
+    std::vector<pt_texture> textures;
+    std::vector<uint8_t> texels;
+    std::vector<float> perlin_ranvec;    // 256 x 3
+    std::vector<int32_t> perlin_perm;    // 3 x 256
     pt_scene_desc desc{};
 };
 
@@ -166,7 +352,9 @@ namespace {
 
 struct SceneBuilder {
     pth_scene &sc;
-    std::map<std::string, std::pair<V3, float>> textures;   // constant textures: colour, alpha
+    std::map<std::string, int> textures;   // id -> index into sc.textures (std::map::emplace: the first id wins)
+    int error_tex = -1;
+    std::string base_dir = ".";            // relative PNG paths are resolved against it (the reference: its working directory)
     std::map<std::string, WrappedMaterial> materials;
     std::map<std::string, WrappedPrim> prims;
     int last_id = 0;
@@ -179,6 +367,7 @@ struct SceneBuilder {
         pt_material m{};
         m.type = type; m.color[0] = color.x; m.color[1] = color.y; m.color[2] = color.z;
         m.alpha = alpha; m.power = power; m.two_sided = two_sided; m.fuzz = fuzz; m.ior = ior;
+        m.texture = -1;
         sc.materials.push_back(m);
         return (int)sc.materials.size() - 1;
     }
@@ -188,21 +377,70 @@ struct SceneBuilder {
         return WrappedMaterial{error_mat, "lambertian"};
     }
 
+    int add_texture(int type, V3 color = v3(0, 0, 0), float alpha = 1.0f, int even = -1, int odd = -1, float scale = 1.0f)
+    {
+        pt_texture t{};
+        t.type = type; t.color[0] = color.x; t.color[1] = color.y; t.color[2] = color.z; t.alpha = alpha;
+        t.even = even; t.odd = odd; t.scale = scale;
+        sc.textures.push_back(t);
+        return (int)sc.textures.size() - 1;
+    }
+    int error_texture()
+    {   // scene_parser.h:98-102: one shared mauve constant_texture
+        if (error_tex < 0) error_tex = add_texture(PT_TEX_CONSTANT, MAUVE);
+        return error_tex;
+    }
+    int texture_by_id(const std::string &id)
+    {   // the reference's textures[id] default-constructs a null pointer for an unknown id and crashes later
+        auto it = textures.find(id);
+        if (it == textures.end()) throw pth::JsonError("unknown texture '" + id + "'");
+        return it->second;
+    }
     void parse_textures(const Json &scene)
-    {   // scene_parser.h:263-330 -- only constant textures are inside the hot-path scope
+    {   // scene_parser.h:263-330
         for (const Json &el : scene["textures"].arr) {
             if (el.value_bool("skip", false)) continue;
             if (!el.contains("id")) throw pth::JsonError("texture without id");
             std::string id = el["id"].as_string();
-            if (!el.contains("data")) { textures.emplace(id, std::make_pair(MAUVE, 1.0f)); continue; }
-            const std::string &type = el["type"].as_string();
+            if (!el.contains("data")) { textures.emplace(id, error_texture()); continue; }
+            const Json &d = el["data"];
+            std::string type = el["type"].as_string();
+            if (type != "checker" && type != "perlin" && type != "png") type = "constant";   // scene.h:71-79: map operator[] -> enum 0
+            int idx;
             if (type == "constant") {
-                const Json &d = el["data"];
-                textures.emplace(id, std::make_pair(json_vec3(d["color"]), (float)d.value("alpha", 1.0)));
+                idx = add_texture(PT_TEX_CONSTANT, json_vec3(d["color"]), (float)d.value("alpha", 1.0));
+            } else if (type == "checker") {
+                auto child = [&](const Json &c) {
+                    if (c.contains("texture")) return texture_by_id(c["texture"].as_string());
+                    return add_texture(PT_TEX_CONSTANT, json_vec3(c["color"]));
+                };
+                int odd = child(d["odd"]);      // scene_parser.h:292-309: odd, then even
+                int even = child(d["even"]);
+                idx = add_texture(PT_TEX_CHECKER, v3(0, 0, 0), 1.0f, even, odd, d["scale"].as_float());
+            } else if (type == "perlin") {
+                idx = add_texture(PT_TEX_PERLIN, v3(0, 0, 0), 1.0f, -1, -1, (float)d.value("scale", 1.0));
             } else {
-                throw pth::JsonError("texture type '" + type + "' is outside the hot-path scope (SURVEY.md 8f-4)");
+                std::string path = d["path"].as_string();
+                if (!path.empty() && path[0] != '/') path = base_dir + "/" + path;
+                int w = 0, h = 0;
+                std::vector<uint8_t> rgba = decode_png(path, w, h);   // lodepng::decode(image, w, h, path): RGBA8
+                idx = add_texture(PT_TEX_IMAGE);
+                sc.textures[idx].width = w; sc.textures[idx].height = h;
+                sc.textures[idx].texel_offset = (int64_t)sc.texels.size();
+                sc.texels.insert(sc.texels.end(), rgba.begin(), rgba.end());
             }
+            textures.emplace(id, idx);
         }
+    }
+    // material / background reference to a texture id: a constant texture is folded into (colour, alpha), anything
+    // else is carried as an index
+    struct TexRef { V3 color; float alpha; int index; };
+    TexRef texture_ref(const std::string &id)
+    {
+        int idx = texture_by_id(id);
+        const pt_texture &t = sc.textures[idx];
+        if (t.type == PT_TEX_CONSTANT) return TexRef{v3(t.color[0], t.color[1], t.color[2]), t.alpha, -1};
+        return TexRef{v3(0, 0, 0), 1.0f, idx};
     }
     void parse_materials(const Json &scene)
     {   // scene_parser.h:332-447
@@ -218,8 +456,10 @@ struct SceneBuilder {
             if (type == "lambertian") {
                 if (d.contains("color")) materials.emplace(id, WrappedMaterial{add_material(PT_MAT_LAMBERTIAN, json_vec3(d["color"])), "lambertian"});
                 else if (d.contains("texture")) {
-                    auto t = textures.at(d["texture"].as_string());
-                    materials.emplace(id, WrappedMaterial{add_material(PT_MAT_LAMBERTIAN, t.first, t.second), "lambertian"});
+                    TexRef t = texture_ref(d["texture"].as_string());
+                    int mi = add_material(PT_MAT_LAMBERTIAN, t.color, t.alpha);
+                    sc.materials[mi].texture = t.index;
+                    materials.emplace(id, WrappedMaterial{mi, "lambertian"});
                 } else materials.emplace(id, error_material());
             } else if (type == "metal") {
                 V3 c = d.contains("color") ? json_vec3(d["color"]) : v3(1, 1, 1);
@@ -233,9 +473,12 @@ struct SceneBuilder {
                 bool two_sided = d.value_bool("two_sided", true);
                 V3 c;
                 float a = 1.0f;
-                if (d.contains("texture")) { auto t = textures.at(d["texture"].as_string()); c = t.first; a = t.second; }
+                int ti = -1;
+                if (d.contains("texture")) { TexRef t = texture_ref(d["texture"].as_string()); c = t.color; a = t.alpha; ti = t.index; }
                 else c = d.contains("color") ? json_vec3(d["color"]) : v3(1, 1, 1);
-                materials.emplace(id, WrappedMaterial{add_material(PT_MAT_DIFFUSE_LIGHT, c, a, power, two_sided), "diffuse_light"});
+                int mi = add_material(PT_MAT_DIFFUSE_LIGHT, c, a, power, two_sided);
+                sc.materials[mi].texture = ti;
+                materials.emplace(id, WrappedMaterial{mi, "diffuse_light"});
             }
             // "isotropic": no case in the reference's switch (scene_parser.h:444-445) -> silently dropped
         }
@@ -439,14 +682,33 @@ struct SceneBuilder {
         }
         if (sc.instances.empty()) throw pth::JsonError("scene has no instances");
         V3 bg = MAUVE;
+        int bg_tex = -1;
         if (scene.contains("world")) {
             const Json &w = scene["world"];
-            if (w.contains("texture")) bg = textures.at(w["texture"].as_string()).first;
+            if (w.contains("texture")) { TexRef t = texture_ref(w["texture"].as_string()); bg = t.color; bg_tex = t.index; }
             else if (w.contains("color")) bg = json_vec3(w["color"]);
         }
-        // the reference's generator state when main() reaches new bvh_node(...): seed 5489 + Perlin statics
+        // the reference's generator state when main() reaches new bvh_node(...): seed 5489, then the static
+        // initialisers of texture.h:180-183 -- perlin_generate() (256 x 3 draws, :99-110) and three
+        // perlin_generate_perm() (255 draws each, :76-97) = PERLIN_STATIC_DRAWS values, which ARE the Perlin tables
         rng = Mt19937(5489u);
-        for (int i = 0; i < PERLIN_STATIC_DRAWS; i++) (void)rng.random_double();
+        sc.perlin_ranvec.resize(768);
+        sc.perlin_perm.resize(768);
+        for (int i = 0; i < 256; i++) {
+            double xr = 2 * rng.random_double() - 1;
+            double yr = 2 * rng.random_double() - 1;
+            double zr = 2 * rng.random_double() - 1;
+            V3 rv = unit(v3((float)xr, (float)yr, (float)zr));
+            sc.perlin_ranvec[3 * i] = rv.x; sc.perlin_ranvec[3 * i + 1] = rv.y; sc.perlin_ranvec[3 * i + 2] = rv.z;
+        }
+        for (int k = 0; k < 3; k++) {
+            int32_t *pm = &sc.perlin_perm[256 * k];
+            for (int i = 0; i < 256; i++) pm[i] = i;
+            for (int i = 255; i > 0; i--) {
+                int target = int(rng.random_double() * (i + 1));
+                std::swap(pm[i], pm[target]);
+            }
+        }
         std::vector<int> order(sc.instances.size()), tmp(sc.instances.size());
         for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
         build_node(order.data(), (int)order.size(), tmp.data());
@@ -480,6 +742,10 @@ struct SceneBuilder {
         d.n_lights = (int)sc.lights.size(); d.lights = sc.lights.data();
         d.camera = cam;
         d.background[0] = bg.x; d.background[1] = bg.y; d.background[2] = bg.z;
+        d.n_textures = (int)sc.textures.size(); d.textures = sc.textures.data();
+        d.texel_bytes = (int64_t)sc.texels.size(); d.texels = sc.texels.data();
+        d.background_texture = bg_tex;
+        d.perlin_ranvec = sc.perlin_ranvec.data(); d.perlin_perm = sc.perlin_perm.data();
     }
 };
 
@@ -558,11 +824,12 @@ extern "C" int pth_config_from_file(const char *path, pth_config *out)
     if (!path || !out) { pth_set_error("pth_config_from_file: null argument"); return -1; }
     return guarded([&] { parse_config(Json::parse(read_file(path)), out); });
 }
+static thread_local std::string g_scene_base_dir = ".";
 extern "C" pth_scene *pth_scene_from_json(const char *text, int32_t width, int32_t height)
 {
     if (!text || width < 1 || height < 1) { pth_set_error("pth_scene_from_json: bad argument"); return nullptr; }
     pth_scene *s = new pth_scene();
-    if (guarded([&] { SceneBuilder(*s).build(Json::parse(text), width, height); })) { delete s; return nullptr; }
+    if (guarded([&] { SceneBuilder b(*s); b.base_dir = g_scene_base_dir; b.build(Json::parse(text), width, height); })) { delete s; return nullptr; }
     return s;
 }
 extern "C" pth_scene *pth_scene_from_file(const char *path, int32_t width, int32_t height)
@@ -570,7 +837,15 @@ extern "C" pth_scene *pth_scene_from_file(const char *path, int32_t width, int32
     if (!path) { pth_set_error("pth_scene_from_file: null path"); return nullptr; }
     std::string text;
     if (guarded([&] { text = read_file(path); })) return nullptr;
-    return pth_scene_from_json(text.c_str(), width, height);
+    // the reference resolves a texture's "path" against its working directory, from which scenes are "scenes/x.json"
+    // and images "assets/y.png": relative image paths are taken from the parent of the scene file's directory
+    std::string p(path);
+    size_t cut = p.find_last_of('/');
+    std::string dir = cut == std::string::npos ? "." : p.substr(0, cut);
+    g_scene_base_dir = dir + "/..";
+    pth_scene *s = pth_scene_from_json(text.c_str(), width, height);
+    g_scene_base_dir = ".";
+    return s;
 }
 extern "C" const pt_scene_desc *pth_scene_desc(const pth_scene *s) { return s ? &s->desc : nullptr; }
 extern "C" void pth_scene_free(pth_scene *s) { delete s; }

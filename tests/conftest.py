@@ -14,8 +14,8 @@ SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"] 
 EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
 # checker / perlin textures, textured emitter and textured World::background
 TEXTURE_SCENES = ["cornell_box_image_light", "textured_room"]
-ALL_SCENES = SCENES + EXTRA_SCENES
-ORACLE_SCENES = ALL_SCENES + TEXTURE_SCENES
+ALL_SCENES = SCENES + EXTRA_SCENES + TEXTURE_SCENES
+ORACLE_SCENES = ALL_SCENES
 
 
 def pytest_configure(config):

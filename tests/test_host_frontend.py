@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(pt.EXPORTS), declared ^ set(pt.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pt_abi_version() == 1
+    assert L.pt_abi_version() == 2
 
 
 @pytest.mark.parametrize("scene", ALL_SCENES)
@@ -54,6 +54,16 @@ def test_flattened_scene_matches_reference_tables(oracle, scene):
         dm = d.materials[i]
         assert dm.type == m.type and tuple(np.float32(x) for x in dm.color) == tuple(m.color)
         assert (np.float32(dm.power), bool(dm.two_sided)) == (m.power, m.two_sided)
+        assert dm.texture == m.texture and np.float32(dm.alpha) == m.alpha
+    # textures: the same table in the same order, the Perlin tables of the static initialisers
+    ts = sc.textures()
+    assert len(ts) == len(P.textures) and d.background_texture == P.background_texture
+    for dt, t in zip(ts, P.textures):
+        assert (dt.type, dt.even, dt.odd, dt.width, dt.height) == (t.type, t.even, t.odd, t.width, t.height)
+        assert tuple(np.float32(x) for x in dt.color) == tuple(t.color) and np.float32(dt.alpha) == t.alpha and np.float32(dt.scale) == t.scale
+    gold = np.load(os.path.join(GOLD, "perlin_tables.npy"))
+    rv, pm = sc.perlin_tables()
+    assert np.array_equal(rv.ravel().view(np.uint32), gold[:768].view(np.uint32)) and np.array_equal(pm.ravel(), gold[768:].astype(np.int32))
     for i, p in enumerate(P.prims):
         dp = d.primitives[i]
         assert (dp.type, dp.material) == (p.type, p.mat)
