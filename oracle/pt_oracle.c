@@ -755,6 +755,13 @@ static rect_t make_rect(float x0, float z0, float x1, float z1, float y, int mat
 }
 
 static void perlin_static_init(mt19937 *g, v3 ranvec[256], int perm[3][256]);
+static int tex_uses_uv(const pto_scene *sc, int ti)
+{   /* does the tree below texture ti reach an image texture (the only kind that reads u, v)? */
+    const tex_t *t = &sc->tex[ti];
+    if (t->type == PTO_TEX_IMAGE) return 1;
+    if (t->type == PTO_TEX_CHECKER) return tex_uses_uv(sc, t->even) || tex_uses_uv(sc, t->odd);
+    return 0;
+}
 pto_scene *pto_scene_create(const pto_material *mats, int nmat, const pto_prim *prims, int nprim,
                             const pto_instance *insts, int ninst, const pto_camera *cam, const float background[3])
 {
@@ -804,12 +811,17 @@ pto_scene *pto_scene_create_textured(const pto_material *mats, int nmat, const p
         sc->mats[i].tex = mats[i].texture;
         if (mats[i].texture >= ntex) goto fail;
         if (mats[i].texture < 0) sc->mats[i].tex = -1;
+        /* an image-textured emitter: the NEE ray of a path that lands on the light lies in the light's plane, rect::hit
+           accepts its NaN t (Q8) and image_texture::alpha indexes with NaN u, v (image.h:46) -- the reference crashes */
+        if (sc->mats[i].tex >= 0 && sc->mats[i].type == PTO_MAT_DIFFUSE_LIGHT && tex_uses_uv(sc, sc->mats[i].tex)) goto fail;
     }
     for (int i = 0; i < nprim; i++) {
         const pto_prim *p = &prims[i];
         prim_t *q = &sc->prims[i];
         q->type = p->type; q->mat = p->mat;
         if (p->mat < 0 || p->mat >= nmat) goto fail;
+        /* sphere::hit / constant_medium::hit leave rec.u, rec.v unset: an image texture there reads indeterminate values */
+        if (sc->mats[p->mat].tex >= 0 && tex_uses_uv(sc, sc->mats[p->mat].tex) && p->type != PTO_PRIM_RECT && p->type != PTO_PRIM_BOX) goto fail;
         switch (p->type) {
         case PTO_PRIM_RECT:
             q->rect = make_rect(p->rect[0], p->rect[1], p->rect[2], p->rect[3], p->rect[4], p->mat, p->plane, p->flipped);

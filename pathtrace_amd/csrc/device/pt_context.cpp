@@ -268,6 +268,14 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         }
         texs[i] = d;
     }
+    for (int i = 0; i < sc->n_materials; i++)
+        if (mats[i].type == PT_MAT_DIFFUSE_LIGHT && mats[i].tex >= 0 && texs[mats[i].tex].uses_uv) {
+            // the NEE ray of a path that lands on the light lies in the light's plane, rect::hit accepts its NaN t and
+            // image_texture::alpha indexes with NaN u, v (image.h:46): the reference crashes on such a scene
+            set_err("pt_create: material %d: an image-textured diffuse_light is not renderable by the reference (NaN u, v "
+                    "index the image out of bounds)", i);
+            return -1;
+        }
     if (any_perlin && (!sc->perlin_ranvec || !sc->perlin_perm)) {
         set_err("pt_create: a perlin texture needs pt_scene_desc::perlin_ranvec / perlin_perm");
         return -1;

@@ -951,9 +951,20 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             k1 = __float_as_uint(s1.w);
             const int id = __float_as_int(h.y);
             if (id < 0) {
-                // miss: sum += beta * world->value(...), constant background (integrator.h:325-336, world.h:27-30)
+                // miss: sum += beta * world->value(u, v, unit_direction) (integrator.h:325-336, world.h:27-30); a constant
+                // background ignores all three.  TAU is "2 * M_PI" unparenthesised (random.h:7), hence the form of u.
+                v3 bg = V(S.bg[0], S.bg[1], S.bg[2]);
+                if (TEX && S.bg_tex >= 0) {
+                    const v3 ud = vunit(B);
+                    float eu = 0.0f, ev = 0.0f, ea;
+                    if (S.tex[S.bg_tex].uses_uv) {
+                        eu = (float)((PT_PI_D + (double)ptm_atan2f(ud.y, ud.x)) / 2 * PT_PI_D);
+                        ev = (float)((double)ptm_acosf(ud.z) / PT_PI_D);
+                    }
+                    tex_eval(S, S.bg_tex, eu, ev, ud, bg, ea);
+                }
                 const float4 rad = st.radiance[slot];
-                const v3 add = vmul(beta, V(S.bg[0], S.bg[1], S.bg[2]));
+                const v3 add = vmul(beta, bg);
                 st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
                 atomicAdd(&sh_ctr[C_MISS], 1u);
             } else {

@@ -268,9 +268,31 @@ def test_async_protocol_and_errors():
     # unsupported scene features are refused loudly at load, not silently approximated
     import json
     s = json.load(open(scene_path("cornell_box")))
-    s["textures"] = [{"id": "n", "type": "perlin", "data": {"scale": 1.0}}]
+    s["textures"] = [{"id": "n", "type": "png", "data": {"path": "assets/does_not_exist.png"}}]   # the reference's own case
     with pytest.raises(pt.PathtraceError):
         pt.Scene(text=json.dumps(s), width=64, height=64)
+    s["textures"] = [{"id": "c", "type": "checker", "data": {"scale": 1.0, "odd": {"texture": "nope"}, "even": {"color": [1, 1, 1]}}}]
+    with pytest.raises(pt.PathtraceError):
+        pt.Scene(text=json.dumps(s), width=64, height=64)
+    # image textures where the reference itself reads indeterminate or out-of-bounds data: on an emitter (NaN u, v from the
+    # in-plane NEE ray of a path that lands on the light) and on a sphere (sphere::hit never sets u, v)
+    import os
+    from conftest import ROOT
+    s = json.load(open(scene_path("image_room")))
+    for t in s["textures"]:
+        if t["type"] == "png":
+            t["data"]["path"] = os.path.join(ROOT, t["data"]["path"])
+    s["materials"][3] = {"id": "lamp", "type": "diffuse_light", "data": {"texture": "poster", "power": 7}}
+    with pytest.raises(pt.PathtraceError, match="image-textured diffuse_light"):
+        pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))
+    s = json.load(open(scene_path("image_room")))
+    for t in s["textures"]:
+        if t["type"] == "png":
+            t["data"]["path"] = os.path.join(ROOT, t["data"]["path"])
+    s["instances"].append({"type": "direct", "primitive": {"type": "sphere", "material": {"id": "poster"}, "radius": 50},
+                           "transform": {"translate": [200, 50, 200]}})
+    with pytest.raises(pt.PathtraceError, match="u, v of a rect"):
+        pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))
     s = json.load(open(scene_path("cornell_box_with_volume")))
     s["primitives"][2]["primitive"] = "white_wall"          # a volume whose boundary is a rect: not implemented on device
     with pytest.raises(pt.PathtraceError):

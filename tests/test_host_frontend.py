@@ -162,3 +162,36 @@ def test_ppm_writer(tmp_path):
     px = np.frombuffer(raw[len(b"P6\n6 4\n255\n"):], np.uint8).reshape(4, 6, 3)
     assert tuple(px[3, 0]) == (255, 255, 255)   # file row 3 = framebuffer row 0
     assert 0 < px[0, 5, 0] < 255 and px[1, 1].sum() == 0
+
+
+def _one_texture_scene(path):
+    return {"camera": {"look_from": [0, 0, -5], "look_at": [0, 0, 0]}, "world": {"color": [0, 0, 0]},
+            "textures": [{"id": "t", "type": "png", "data": {"path": path}}],
+            "materials": [{"id": "m", "type": "lambertian", "data": {"texture": "t"}}], "primitives": [],
+            "instances": [{"type": "direct", "primitive": {"type": "rect", "material": {"id": "m"}, "size": [1, 1]}}]}
+
+
+@pytest.mark.parametrize("name", ["poster", "sky", "lamp", "palette", "grey"])
+def test_png_reader_matches_the_test_side_reader(name):
+    # what lodepng::decode hands to from_4byte_vector (scene_parser.h:39-55): RGBA8, row 0 first.  The assets cover all
+    # five colour types, all five row filters, stored / fixed / dynamic deflate blocks, tRNS and split IDAT chunks
+    # (tools/author_scenes.py); the checker is an independent reader on Python's zlib (oracle/scene_params.py).
+    from oracle import scene_params as sp
+
+    path = os.path.join(ROOT, "assets", name + ".png")
+    w, h, rgba = sp.decode_png(path)
+    sc = pt.Scene(text=json.dumps(_one_texture_scene(path)), width=8, height=8)
+    t = sc.textures()[0]
+    assert (t.type, t.width, t.height, t.texel_offset) == (3, w, h, 0)
+    assert sc.texel_bytes() == rgba and len(rgba) == 4 * w * h
+
+
+def test_png_errors_are_loud(tmp_path):
+    for body in (b"", b"not a png at all", open(os.path.join(ROOT, "assets", "sky.png"), "rb").read()[:90]):
+        p = tmp_path / "bad.png"
+        p.write_bytes(body)
+        with pytest.raises(pt.PathtraceError):
+            pt.Scene(text=json.dumps(_one_texture_scene(str(p))), width=8, height=8)
+    # relative paths resolve against the parent of the scene file's directory (the reference: its working directory)
+    sc = pt.Scene(scene_path("image_room"), 8, 8)
+    assert [t.type for t in sc.textures()] == [3, 3, 0, 1]

@@ -272,7 +272,107 @@ scenes["textured_room"] = {
     ],
 }
 
+# ---- image textures (image.h): small PNG assets written here, pixel content from closed formulas ----------------------
+def write_png(path, w, h, ctype, pixel, palette=None, trns=None, level=6, strategy=0):
+    """8-bit non-interlaced PNG; rows cycle through the five filter types so a reader has to undo all of them."""
+    import struct
+    import zlib
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    rows = [[pixel(x, y) for x in range(w)] for y in range(h)]
+    raw = bytearray()
+    prev = [0] * (w * ch)
+    for y in range(h):
+        cur = [c for px in rows[y] for c in px]
+        ft = y % 5
+        raw.append(ft)
+        for i, v in enumerate(cur):
+            a = cur[i - ch] if i >= ch else 0
+            b = prev[i]
+            c = prev[i - ch] if i >= ch else 0
+            if ft == 0:
+                pr = 0
+            elif ft == 1:
+                pr = a
+            elif ft == 2:
+                pr = b
+            elif ft == 3:
+                pr = (a + b) >> 1
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            raw.append((v - pr) & 255)
+        prev = cur
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xffffffff)
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+    data = co.compress(bytes(raw)) + co.flush()
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(c for rgb in palette for c in rgb))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    out += chunk(b"IDAT", data[:len(data) // 2]) + chunk(b"IDAT", data[len(data) // 2:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def write_assets():
+    import zlib
+    adir = os.path.join(HERE, "..", "assets")
+    os.makedirs(adir, exist_ok=True)
+    # poster: RGBA, colour ramps with a transparent-ish diagonal band
+    write_png(os.path.join(adir, "poster.png"), 16, 12, 6,
+              lambda x, y: (40 + 13 * x, 250 - 17 * y, (x * y * 7) % 256, 255 if (x + y) % 5 else 96))
+    # sky: RGB environment map, brighter towards the top rows
+    write_png(os.path.join(adir, "sky.png"), 32, 16, 2,
+              lambda x, y: (30 + 6 * y + (x % 4) * 9, 60 + 9 * y, 235 - 5 * y - (x % 3) * 20))
+    # grey + alpha, fixed-Huffman deflate blocks (reader test; an image-textured emitter crashes the reference)
+    write_png(os.path.join(adir, "lamp.png"), 8, 8, 4, lambda x, y: (255 - 20 * ((x + y) % 4), 255 if (x ^ y) & 1 else 128),
+              strategy=zlib.Z_FIXED)
+    # decoder-only cases: palette + tRNS (stored deflate blocks), grey with a transparent key
+    write_png(os.path.join(adir, "palette.png"), 7, 5, 3, lambda x, y: ((x + 2 * y) % 6,),
+              palette=[(255, 0, 0), (0, 255, 0), (0, 0, 255), (255, 255, 0), (9, 99, 199), (0, 0, 0)], trns=[255, 128, 0], level=0)
+    write_png(os.path.join(adir, "grey.png"), 9, 4, 0, lambda x, y: ((x * 31 + y * 17) % 256,), trns=[0, 48])
+
+
+# Our own coverage scene for image textures: an image-textured lambertian floor and box (rect u, v incl. the reference's
+# v = (zh - x0) / (z1 - z0) slip, primitive.h:207), an image inside a checker, and an image as World::background looked
+# up by direction (integrator.h:327-332 with TAU = 2 * M_PI unparenthesised).  The light is NOT image-textured: the
+# reference crashes on that as soon as a path lands on the light (its NEE ray lies in the light's plane, rect::hit
+# accepts the NaN t, and image_texture indexes with NaN u, v -- image.h:46); the product refuses such a scene.
+scenes["image_room"] = {
+    "camera": camera(-750.0),
+    "world": {"texture": "sky"},
+    "assets": [],
+    "textures": [
+        {"id": "poster", "type": "png", "data": {"path": "assets/poster.png"}},
+        {"id": "sky", "type": "png", "data": {"path": "assets/sky.png"}},
+        const_tex("white", (0.73, 0.73, 0.73)),
+        {"id": "mix", "type": "checker", "data": {"scale": 0.03, "odd": {"texture": "poster"}, "even": {"texture": "white"}}},
+    ],
+    "materials": [
+        lambertian("red", (0.65, 0.05, 0.05)),
+        {"id": "poster", "type": "lambertian", "data": {"texture": "poster"}},
+        {"id": "mix", "type": "lambertian", "data": {"texture": "mix"}},
+        {"id": "lamp", "type": "diffuse_light", "data": {"color": [1.0, 0.9, 0.8], "power": 7}},
+    ],
+    "primitives": [
+        {"id": "floor", "type": "rect", "material": {"id": "poster"}, "size": [555, 555]},
+        {"id": "back", "type": "rect", "material": {"id": "mix"}, "size": [555, 555]},
+    ],
+    "instances": [
+        ref("floor", translate=[277.5, 0.0, 277.5]),
+        ref("back", rotate=[1.5, 0, 0], translate=[277.5, 277.5, 555]),
+        direct({"type": "rect", "material": {"id": "red"}, "size": [555, 555], "align": "yz"}, translate=[0, 277.5, 277.5]),
+        direct({"type": "box", "material": {"id": "poster"}, "size": [165, 330, 165]},
+               translate=[347.5, 165, 377.5], rotate=[0.0, 0.05, 0.0]),
+        direct({"type": "rect", "material": {"id": "lamp"}, "size": [260, 220]}, translate=[250, 500.0, 250], rotate=[1.0, 0, 0]),
+    ],
+}
+
 if __name__ == "__main__":
+    write_assets()
     os.makedirs(OUT, exist_ok=True)
     for name, sc in scenes.items():
         with open(os.path.join(OUT, name + ".json"), "w") as f:
