@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import pathtrace_amd as pt
-from conftest import ALL_SCENES, EXTRA_SCENES, SCENES, scene_path
+from conftest import ALL_SCENES, EXTRA_SCENES, SCENES, TEXTURE_SCENES, scene_path
 
 pytestmark = pytest.mark.gpu
 
@@ -77,9 +77,10 @@ def test_bit_exact_config1_size_200x200x16(oracle, scene):
     assert_counters(gc, oc, scene)
 
 
-@pytest.mark.parametrize("scene", EXTRA_SCENES)
+@pytest.mark.parametrize("scene", EXTRA_SCENES + TEXTURE_SCENES)
 def test_bit_exact_extra_scenes_16x9(oracle, scene):
-    # beyond BASELINE: sphere lights with cone sampling + metal, dielectric spheres, a room-filling volume
+    # beyond BASELINE: sphere lights with cone sampling + metal, dielectric spheres, a room-filling volume;
+    # (8f-4): checker / perlin / image textures, textured emitter, textured and image World::background
     w, h, spp = 160, 90, 8
     ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=5)
     gpu, gc = gpu_render(scene, w, h, spp, seed=5)
@@ -213,7 +214,7 @@ def test_seed_changes_the_stream_but_not_the_estimate(oracle):
     assert np.allclose(a.mean(axis=(0, 1)), b.mean(axis=(0, 1)), rtol=0.03)
 
 
-@pytest.mark.parametrize("scene", SCENES)
+@pytest.mark.parametrize("scene", SCENES + TEXTURE_SCENES)
 def test_statistical_agreement_with_reference_fixture(scene):
     # L3 of the parity ladder: same estimator, different random streams.  Like for like: the GPU renders
     # BASELINE config 1 (200x200x16) with 8 seeds; the REAL reference's fixture (one draw from the reference's
