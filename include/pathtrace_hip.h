@@ -184,7 +184,7 @@ int pt_read_last_batch_radiance(pt_ctx *ctx, float *rgba, size_t max_records, si
 
 /* Validation hook: World::hit (world.h:17-20, with the integrator's t range (0.001, FLT_MAX)) for caller-supplied
  * rays, through the very traversal code the render kernels use.  n origins (float[3n]); rays_per_origin = 1 uses the
- * extension-ray instantiation, 4 the shared-origin shadow-ray instantiation (dirs = float[3 * n * rays_per_origin]).
+ * extension-ray instantiation, 2 and 4 the shared-origin instantiations of the shadow rays (dirs = float[3 * n * rays_per_origin]).
  * k0, k1, vol_dim = stream RNG key and dimension base for constant_medium free-flight draws.  Outputs per ray:
  * t and id = instance*8 + face, or -1 for a miss. */
 int pt_trace_rays(pt_ctx *ctx, int64_t n, int32_t rays_per_origin, const float *origins, const float *dirs,

@@ -825,7 +825,7 @@ extern "C" int pt_get_counters(pt_ctx *c, pt_counters *out)
 extern "C" int pt_trace_rays(pt_ctx *c, int64_t n, int32_t nr, const float *origins, const float *dirs, uint32_t k0, uint32_t k1,
                              uint32_t vol_dim, float *t_out, int32_t *id_out)
 {
-    if (!c || n < 1 || (nr != 1 && nr != 4) || !origins || !dirs || !t_out || !id_out) { set_err("pt_trace_rays: bad argument"); return -1; }
+    if (!c || n < 1 || (nr != 1 && nr != 2 && nr != 4) || !origins || !dirs || !t_out || !id_out) { set_err("pt_trace_rays: bad argument"); return -1; }
     if (pt_wait(c)) return -1;
     float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
     int *d_i = nullptr;

@@ -1306,6 +1306,7 @@ void launch_trace(const DScene &S, long long n, int nr, const float *org, const 
     const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
     const size_t lds = (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
     if (nr == 4) hipLaunchKernelGGL(k_trace<4>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
+    else if (nr == 2) hipLaunchKernelGGL(k_trace<2>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
     else hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)

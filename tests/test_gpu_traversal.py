@@ -88,14 +88,16 @@ def test_world_hit_matches_oracle_on_adversarial_rays(oracle, scene):
     if scene.startswith("cornell_box"):
         assert np.isnan(t[ids >= 0]).sum() > 0, "the ray set must contain in-plane rays that the reference reports as NaN-t hits"
     assert (ids < 0).sum() > 100 and (ids >= 0).sum() > 5000
-    # four rays sharing an origin: group consecutive directions (any grouping is a valid test)
-    n4 = (len(o) // 4) * 4
-    d4 = d[:n4].reshape(-1, 4, 3)
-    o4 = o[:n4:4]
-    t4, id4 = r.trace_rays(o4, d4, k0, k1, vd)
-    for k in range(4):
-        hit, ot, inst = osc.world_hit_stream(o4, d4[:, k], k0, k1, vd + 16 * k)
-        ginst = np.where(id4[:, k] >= 0, id4[:, k] >> 3, -1)
-        assert np.array_equal(ginst, inst), (k, (ginst != inst).sum())
-        assert (same_t(t4[:, k], ot) | (hit == 0)).all(), k
+    # several rays sharing an origin (any grouping of consecutive directions is a valid test): 4 = the four-wide
+    # instantiation, 2 = the two-ray one k_connect launches by default
+    for nr in (4, 2):
+        nn = (len(o) // nr) * nr
+        dn = d[:nn].reshape(-1, nr, 3)
+        on = o[:nn:nr]
+        tn, idn = r.trace_rays(on, dn, k0, k1, vd)
+        for k in range(nr):
+            hit, ot, inst = osc.world_hit_stream(on, dn[:, k], k0, k1, vd + 16 * k)
+            ginst = np.where(idn[:, k] >= 0, idn[:, k] >> 3, -1)
+            assert np.array_equal(ginst, inst), (nr, k, (ginst != inst).sum())
+            assert (same_t(tn[:, k], ot) | (hit == 0)).all(), (nr, k)
     r.close()
