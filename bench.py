@@ -159,6 +159,20 @@ def main():
                 traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the binding resource is the vector ALU, not HBM: share of the one-wide VALU issue rate this kernel sustained in
+        # the serialised counter pass (tools/profile_gpu.sh pass 4 -> profiles/*_instruction_mix.json)
+        valu = None
+        try:
+            import glob
+            mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instruction_mix.json")))
+            if mixes:
+                mk = json.load(open(mixes[-1])).get(dom)
+                if mk:
+                    valu = {"valu_issue_fraction": mk["valu_issue_fraction"], "valu_per_wave": mk["valu_per_wave"],
+                            "salu_over_valu": mk["salu_over_valu"], "effective_clock_GHz": mk["effective_clock_GHz"],
+                            "source": "profiles/" + os.path.basename(mixes[-1])}
+        except Exception:
+            valu = None
         # the same kernel without a second batch sharing the chip: a short extra pass on a single-lane context (the timed
         # region above runs two batches in flight, which is faster overall but stretches every individual launch)
         solo = None
@@ -188,6 +202,7 @@ def main():
                     "bytes_per_launch_model": round(model_bytes[dom] / launches, 1),
                     "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
                     "single_batch_in_flight": solo,
+                    "valu": valu,
                     "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
                     "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)}
 

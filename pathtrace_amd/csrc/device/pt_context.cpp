@@ -74,7 +74,7 @@ struct pt_ctx {
     DScene S{};
     DStreams st{};
     int64_t P = 0;       // path slots
-    int seg_cap = 2048;
+    int seg_cap = 4096;
     int n_seg_max = 0;
     std::vector<void *> allocs;
     hipStream_t own_stream = nullptr, stream = nullptr;   // lane 0's stream (stream may be caller-owned)
@@ -428,7 +428,8 @@ static int alloc_streams(pt_ctx *c)
 {
     int64_t want = c->cfg.max_paths_in_flight > 0 ? c->cfg.max_paths_in_flight : (int64_t)8 << 20;
     want = std::max<int64_t>(want, 64);
-    c->seg_cap = 2048;
+    c->seg_cap = 4096;   // measured on cornell_box 1080p: 1024 -2.4 %, 2048 -1.4 %, 4096 best, 8192 / 16384 -0.3 %
+    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) c->seg_cap = v; }
     c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
     c->P = (int64_t)c->n_seg_max * c->seg_cap;
     const size_t P = (size_t)c->P;

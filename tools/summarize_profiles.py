@@ -47,6 +47,41 @@ def pmc_per_launch(d, counter):
     return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items() if v}
 
 
+def insts_per_kernel(d):
+    """Per kernel, over all its dispatches of the counter pass (dispatches are serialised there): instruction counts per
+    wave and the share of the one-wide VALU issue rate the kernel sustained.  A wave64 VALU instruction occupies its SIMD
+    for 4 cycles, so a chip of 256 CUs x 4 SIMDs issues at most 1024 * f / 4 of them per second; f is taken from
+    GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch time, i.e. the clock the dispatch actually ran at."""
+    f = find(d, "counter_collection.csv")
+    if not f:
+        return {}
+    acc = defaultdict(lambda: defaultdict(float))
+    dur = defaultdict(dict)
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = kname(row.get("Kernel_Name", ""))
+            if not k:
+                continue
+            acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            dur[k][row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+    out = {}
+    for k, c in acc.items():
+        t = sum(dur[k].values())
+        waves = max(c.get("SQ_WAVES", 0.0), 1.0)
+        clock = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t if t > 0 else 0.0
+        peak = 1024.0 * clock / 4.0
+        out[k] = {"dispatches": len(dur[k]), "seconds": round(t, 6), "waves": int(waves),
+                  "valu_per_wave": round(c.get("SQ_INSTS_VALU", 0) / waves, 1),
+                  "salu_per_wave": round(c.get("SQ_INSTS_SALU", 0) / waves, 1),
+                  "smem_per_wave": round(c.get("SQ_INSTS_SMEM", 0) / waves, 1),
+                  "lds_per_wave": round(c.get("SQ_INSTS_LDS", 0) / waves, 1),
+                  "effective_clock_GHz": round(clock / 1e9, 3),
+                  "valu_insts_per_s": round(c.get("SQ_INSTS_VALU", 0) / t, 1) if t > 0 else 0.0,
+                  "valu_issue_fraction": round(c.get("SQ_INSTS_VALU", 0) / t / peak, 4) if t > 0 and peak > 0 else None,
+                  "salu_over_valu": round(c.get("SQ_INSTS_SALU", 0) / max(c.get("SQ_INSTS_VALU", 0), 1.0), 3)}
+    return out
+
+
 def main():
     tag, d = sys.argv[1], sys.argv[2]
     out = os.path.join(d, "summary_" + tag)
@@ -69,6 +104,13 @@ def main():
             res[k] = {"launches_sampled": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
     json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+    ins = insts_per_kernel(os.path.join(d, tag + "_pmc_insts"))
+    if ins:
+        ins["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS "
+                       "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/profile_gpu.sh " + tag + "), bench.py --steps 4 "
+                       "--warmup 1; valu_issue_fraction = wave64 VALU instructions per second / (1024 SIMDs * clock / 4)")
+        json.dump(ins, open(os.path.join(out, tag + "_instruction_mix.json"), "w"), indent=1)
+        print(json.dumps({k: v for k, v in ins.items() if k != "note"}))
     print(json.dumps({k: v for k, v in res.items() if k != "note"}))
     if ks:
         print(open(ks).read()[:1500])
