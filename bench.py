@@ -83,11 +83,6 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
 
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
-    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * SPP_PER_STEP)
-    # render straight into a torch tensor so that the final reduce needs no copy
-    fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
-    r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
-
     spp_step = SPP_PER_STEP * n
     from pathtrace_amd.distributed import measure_tile_costs, reduce_framebuffer, tiles_for_rank
     if n == 1:
@@ -97,8 +92,16 @@ def main():
         # per pixel per tile (identical integers on every rank) and derives the same cost-balanced ownership map
         costs = None
         if os.environ.get("PT_BENCH_ROUND_ROBIN") != "1":
-            costs = measure_tile_costs(r, pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE))
+            planner = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=TILE * TILE)
+            costs = measure_tile_costs(planner, pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE))
+            planner.close()
         my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
+    # path slots for exactly one step of this rank's pixels: one wavefront batch per step (at N = 1: W*H*16 = 33 M)
+    my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
+    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_step)
+    # render straight into a torch tensor so that the final reduce needs no copy
+    fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
     def step(i):
         r.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
@@ -178,7 +181,7 @@ def main():
         solo = None
         try:
             os.environ["PATHTRACE_HIP_LANES"] = "1"
-            r1 = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * SPP_PER_STEP)
+            r1 = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_step)
             r1.render_tiles_async(my_tiles, 0, spp_step)
             r1.wait()
             r1.set_profiling(True)
