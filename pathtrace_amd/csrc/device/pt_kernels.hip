@@ -394,7 +394,24 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             const bool ident = (op_slot != 0) && all_finite;
             const v3 Al = ident ? V(m[3] + A.x, m[7] + A.y, m[11] + A.z) : xf_point(m, A);
 #define XF_DIR(b) (ident ? (b) : xf_linear(m, (b)))
-            if (kind == OP_LEAF_BOX) {
+            if (kind <= OP_LEAF_RECT_YZ) {   // the three rect alignments first: the most frequent leaf (rect::hit primitive.h:186-225)
+                float ox, opl, oz;
+                if (kind == OP_LEAF_RECT_XY) rect_axes<0>(Al, ox, opl, oz);
+                else if (kind == OP_LEAF_RECT_YZ) rect_axes<2>(Al, ox, opl, oz);
+                else rect_axes<1>(Al, ox, opl, oz);
+                const float num = q1[1] - opl;
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = XF_DIR(B[r]);
+                    float t, e;
+                    if (kind == OP_LEAF_RECT_XY) e = rect_excess<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else if (kind == OP_LEAF_RECT_YZ) e = rect_excess<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    else e = rect_excess<1>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
+                    const bool hit = !(e > 0.0f) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? t : cur_t[r];
+                }
+            } else if (kind == OP_LEAF_BOX) {
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const v3 Bl = XF_DIR(B[r]);
@@ -440,23 +457,6 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     const bool hit = (disc > 0) && (ha || hb) && (pc >= skip[r]);
                     cur_id[r] = hit ? op_id_base : -1;
                     cur_t[r] = hit ? (ha ? ta : tb) : cur_t[r];
-                }
-            } else {   // the three rect alignments (rect::hit primitive.h:186-225)
-                float ox, opl, oz;
-                if (kind == OP_LEAF_RECT_XY) rect_axes<0>(Al, ox, opl, oz);
-                else if (kind == OP_LEAF_RECT_YZ) rect_axes<2>(Al, ox, opl, oz);
-                else rect_axes<1>(Al, ox, opl, oz);
-                const float num = q1[1] - opl;
-#pragma unroll
-                for (int r = 0; r < NR; r++) {
-                    const v3 Bl = XF_DIR(B[r]);
-                    float t, e;
-                    if (kind == OP_LEAF_RECT_XY) e = rect_excess<0>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else if (kind == OP_LEAF_RECT_YZ) e = rect_excess<2>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    else e = rect_excess<1>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl, T_MIN, T_MAX, t);
-                    const bool hit = !(e > 0.0f) && (pc >= skip[r]);
-                    cur_id[r] = hit ? op_id_base : -1;
-                    cur_t[r] = hit ? t : cur_t[r];
                 }
             }
         }
