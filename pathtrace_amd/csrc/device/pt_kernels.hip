@@ -894,7 +894,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
 // material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
 // continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
 // ------------------------------------------------------------------------------------------------
-template <bool TEX>
+// LM: how the light of an NEE sample is found -- 1: the scene has one light (scalar records), 2: two lights (both records
+// scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
+// of the others.
+template <bool TEX, int LM>
 __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -1061,9 +1064,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
             // tr: the light's transform is a pure translation and every hit point of this wave is finite (same exactness
             // argument as in world_hit_n): local point = translation + p, directions are unchanged
-            auto light_sample = [&](const uint32_t k, const uint32_t kb, const int light, const bool tr) {
-                const DInst &lin = S.insts[light];
-                const DPrim &lpr = S.prims[lin.prim];
+            auto light_sample = [&](const uint32_t k, const uint32_t kb, const DInst &lin, const DPrim &lpr, const bool tr) {
                 const v3 ol = tr ? V(lin.inv[3] + hp.x, lin.inv[7] + hp.y, lin.inv[11] + hp.z) : xf_point(lin.inv, hp);
                 const v3 dl = prim_random(lpr, ol, k0, k1, kb + 1);                       // instance::random primitive.h:338-342
                 const v3 ldir = tr ? dl : xf_linear(lin.fwd, dl);
@@ -1080,15 +1081,37 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                 sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                 sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
             };
-            if (S.n_lights == 1) {
-                const int light = S.lights[0];
-                const bool tr = S.insts[light].ident && wave_finite;
-                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), light, tr);
+            if (LM == 1) {
+                const DInst &lin = S.insts[S.lights[0]];
+                const bool tr = lin.ident && wave_finite;
+                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, S.prims[lin.prim], tr);
+            } else if (LM == 2) {
+                // two lights (BASELINE config 3): both records come in by scalar loads and every lane selects the fields of the
+                // one it drew -- a few dozen v_cndmask instead of per-lane table gathers
+                const DInst &ia = S.insts[S.lights[0]], &ib = S.insts[S.lights[1]];
+                const DPrim &pa = S.prims[ia.prim], &pb = S.prims[ib.prim];
+                for (uint32_t k = 0; k < L; k++) {
+                    const uint32_t kb = base + NV + k * (3u + NV);
+                    const bool second = (int)(rnd(k0, k1, kb + 0) * 2.0) != 0;            // world.h:31-35
+                    DInst lin;
+                    DPrim lpr;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) { lin.inv[i] = second ? ib.inv[i] : ia.inv[i]; lin.fwd[i] = second ? ib.fwd[i] : ia.fwd[i]; }
+                    lpr.type = second ? pb.type : pa.type;
+                    lpr.cx = second ? pb.cx : pa.cx; lpr.cy = second ? pb.cy : pa.cy; lpr.cz = second ? pb.cz : pa.cz;
+                    lpr.radius = second ? pb.radius : pa.radius;
+                    lpr.r[0].x0 = second ? pb.r[0].x0 : pa.r[0].x0; lpr.r[0].z0 = second ? pb.r[0].z0 : pa.r[0].z0;
+                    lpr.r[0].x1 = second ? pb.r[0].x1 : pa.r[0].x1; lpr.r[0].z1 = second ? pb.r[0].z1 : pa.r[0].z1;
+                    lpr.r[0].y = second ? pb.r[0].y : pa.r[0].y; lpr.r[0].plane = second ? pb.r[0].plane : pa.r[0].plane;
+                    lpr.r[0].ny = second ? pb.r[0].ny : pa.r[0].ny;
+                    light_sample(k, kb, lin, lpr, false);
+                }
             } else {
                 for (uint32_t k = 0; k < L; k++) {
                     const uint32_t kb = base + NV + k * (3u + NV);
                     const int idx = (int)(rnd(k0, k1, kb + 0) * (double)S.n_lights);   // world.h:31-35
-                    light_sample(k, kb, S.lights[idx], false);
+                    const DInst &lin = S.insts[S.lights[idx]];
+                    light_sample(k, kb, lin, S.prims[lin.prim], false);
                 }
             }
         }
@@ -1274,8 +1297,12 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    if (S.textured) hipLaunchKernelGGL(k_shade<true>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+#define PT_LAUNCH_SHADE(TEX, LM) hipLaunchKernelGGL((k_shade<TEX, LM>), grid, block, 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
+    const int lm = S.n_lights == 1 ? 1 : (S.n_lights == 2 ? 2 : 0);   // cornell_box_small_lights 1080p: 2 = 21.1, 0 = 20.8 Grays/s
+    if (S.textured) { if (lm == 1) PT_LAUNCH_SHADE(true, 1); else if (lm == 2) PT_LAUNCH_SHADE(true, 2); else PT_LAUNCH_SHADE(true, 0); }
+    else { if (lm == 1) PT_LAUNCH_SHADE(false, 1); else if (lm == 2) PT_LAUNCH_SHADE(false, 2); else PT_LAUNCH_SHADE(false, 0); }
+#undef PT_LAUNCH_SHADE
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
 {
