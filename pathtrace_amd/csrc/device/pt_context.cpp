@@ -401,6 +401,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     if (dev_upload(c, &S.tex, texs) || dev_upload(c, &S.texels, texels) || dev_upload(c, &S.ranvec, ranvec) || dev_upload(c, &S.perm, perm))
         return -1;
     S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
+    S.geom_all = 0;
+    for (const DOp &op : ops) S.geom_all |= (op.kind == OP_LEAF_SPHERE || op.kind == OP_LEAF_VOLBOX);
     S.textured = S.bg_tex >= 0;
     for (const DMat &m : mats) S.textured |= m.tex >= 0;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||

@@ -96,6 +96,7 @@ struct DScene {
     const float4 *ranvec;        // perlin::ranvec[256] (xyz), perlin perm_x / perm_y / perm_z [3][256]
     const int32_t *perm;
     int32_t bg_tex;              // World::background texture, -1 = the constant bg[] below
+    int32_t geom_all;            // the program has sphere or constant_medium leaves: launch the <GA = true> traversal
     int32_t textured;            // some material or the background uses the texture table: launch the <TEX = true> kernels
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
     int32_t stack_depth;         // short-stack slots the program uses

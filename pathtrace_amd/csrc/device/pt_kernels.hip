@@ -302,7 +302,10 @@ DEVI void box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t
 // skip = max(skip, miss ? op_a : 0) leaves masked rays alone; (iii) stack slots written inside a skipped subtree are
 // dead for that ray, so pushes need no mask.
 // ------------------------------------------------------------------------------------------------
-template <int NR>
+// GA ("all geometry"): the scene has sphere or constant_medium leaves.  Scenes of rects and boxes only (all BASELINE
+// Cornell boxes but the volume one) run the GA = false instantiations, which carry neither the code nor the registers of
+// those leaves (k_extend 56 -> 43 VGPRs, k_connect<2> 79 -> 70).
+template <int NR, bool GA>
 DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                       const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -422,7 +425,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     cur_id[r] = hit ? (op_id_base + face) : -1;
                     cur_t[r] = hit ? t : cur_t[r];
                 }
-            } else if (kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
+            } else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     const v3 Bl = XF_DIR(B[r]);
@@ -443,7 +446,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     cur_id[r] = hit ? op_id_base : -1;
                     cur_t[r] = hit ? (t1v + hit_distance / dlen) : cur_t[r];
                 }
-            } else if (kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95
+            } else if (GA && kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95
                 const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
                 const float c = vdot(oc, oc) - q1[0] * q1[0];
 #pragma unroll
@@ -834,6 +837,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of every live path's ray (integrator.h:192-193)
 // ------------------------------------------------------------------------------------------------
+template <bool GA>
 __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
-        world_hit_n<1>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
+        world_hit_n<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0 && n_rays) {
@@ -1143,8 +1147,8 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 }
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
-template <int NR, bool TEX>
-__global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+template <int NR, bool TEX, bool GA>
+__global__ __launch_bounds__(PT_BLOCK, GA ? 6 : 7) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
@@ -1193,7 +1197,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__
                     coef[k] = V(d.w, e.x, e.y);
                     vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
                 }
-                world_hit_n<R>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit_n<R, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
@@ -1207,7 +1211,7 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_connect(DScene S, const DOp *__
                 const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
                 float t[1];
                 int id[1];
-                world_hit_n<1>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit_n<1, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
                 if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
@@ -1249,7 +1253,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 // ------------------------------------------------------------------------------------------------
 // trace: World::hit for caller-supplied rays (pt_trace_rays), same traversal as k_extend / k_connect
 // ------------------------------------------------------------------------------------------------
-template <int NR>
+template <int NR, bool GA>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restrict__ t_ops, long long n, const float *__restrict__ org,
                                                     const float *__restrict__ dir, uint32_t k0, uint32_t k1, uint32_t vol_dim,
                                                     float *t_out, int *id_out)
@@ -1269,7 +1273,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
         B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
         vd[r] = vol_dim + (uint32_t)r * 16u;
     }
-    world_hit_n<NR>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
+    world_hit_n<NR, GA>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
     if (valid) {
 #pragma unroll
         for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }
@@ -1293,7 +1297,8 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const size_t lds = (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    hipLaunchKernelGGL(k_extend, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    if (S.geom_all) hipLaunchKernelGGL(k_extend<true>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
@@ -1314,17 +1319,11 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
-#define PT_LAUNCH_CONNECT(NR, TEX) hipLaunchKernelGGL((k_connect<NR, TEX>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
-    if (S.textured) {   // k_connect<0> (wave-per-hit variant) is not instantiated with textures: one ray per lane instead
-        if (nr == 4) PT_LAUNCH_CONNECT(4, true);
-        else if (nr == 2) PT_LAUNCH_CONNECT(2, true);
-        else PT_LAUNCH_CONNECT(1, true);
-    } else {
-        if (nr == 4) PT_LAUNCH_CONNECT(4, false);
-        else if (nr == 2) PT_LAUNCH_CONNECT(2, false);
-        else if (nr == 1) PT_LAUNCH_CONNECT(1, false);
-        else PT_LAUNCH_CONNECT(0, false);
-    }
+#define PT_LAUNCH_CONNECT(NR, TEX, GA) hipLaunchKernelGGL((k_connect<NR, TEX, GA>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
+#define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA); else PT_LAUNCH_CONNECT(1, TEX, GA); }
+    if (S.textured) { if (S.geom_all) PT_LAUNCH_CONNECT_NR(true, true) else PT_LAUNCH_CONNECT_NR(true, false) }
+    else { if (S.geom_all) PT_LAUNCH_CONNECT_NR(false, true) else PT_LAUNCH_CONNECT_NR(false, false) }
+#undef PT_LAUNCH_CONNECT_NR
 #undef PT_LAUNCH_CONNECT
 }
 void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
@@ -1332,9 +1331,10 @@ void launch_trace(const DScene &S, long long n, int nr, const float *org, const 
 {
     const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
     const size_t lds = (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
-    if (nr == 4) hipLaunchKernelGGL(k_trace<4>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
-    else if (nr == 2) hipLaunchKernelGGL(k_trace<2>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
-    else hipLaunchKernelGGL(k_trace<1>, dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out);
+#define PT_LAUNCH_TRACE(NR, GA) hipLaunchKernelGGL((k_trace<NR, GA>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out)
+    if (S.geom_all) { if (nr == 4) PT_LAUNCH_TRACE(4, true); else if (nr == 2) PT_LAUNCH_TRACE(2, true); else PT_LAUNCH_TRACE(1, true); }
+    else { if (nr == 4) PT_LAUNCH_TRACE(4, false); else if (nr == 2) PT_LAUNCH_TRACE(2, false); else PT_LAUNCH_TRACE(1, false); }
+#undef PT_LAUNCH_TRACE
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
