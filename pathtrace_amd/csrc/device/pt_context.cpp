@@ -585,7 +585,7 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     DBatch bb = b;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
         // segments merge pairwise from one bounce to the next (pt_device.h DBatch) until one is left
-        static const bool no_merge = getenv("PT_NO_MERGE") != nullptr;
+        static const bool no_merge = getenv("PATHTRACE_HIP_NO_MERGE") != nullptr;
         if (bb.n_seg > 1 && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
         else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
         { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm); }
