@@ -831,6 +831,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
     if (threadIdx.x == 0) {
         q.count[seg] = n;
         if (n) atomicAdd(&counter_bank(st.counters)->camera_samples, (unsigned long long)n);
+        // max_bounces = 0: the integrator's loop never runs and every path ends at the depth limit with no radiance
+        if (n && S.max_bounces == 0) atomicAdd(&counter_bank(st.counters)->term_bounce_limit, (unsigned long long)n);
     }
 }
 
