@@ -798,7 +798,7 @@ pto_scene *pto_scene_create_textured(const pto_material *mats, int nmat, const p
     sc->mats = (mat_t *)calloc((size_t)nmat, sizeof(mat_t));
     sc->prims = (prim_t *)calloc((size_t)nprim, sizeof(prim_t));
     sc->insts = (inst_t *)calloc((size_t)ninst, sizeof(inst_t));
-    sc->nodes = (node_t *)calloc((size_t)ninst + 1, sizeof(node_t));
+    sc->nodes = (node_t *)calloc(2 * (size_t)ninst + 2, sizeof(node_t)) /* a one-leaf range still makes a node (bvh.h:142): up to 2n - 1 nodes */;
     sc->lights = (int *)calloc((size_t)ninst, sizeof(int));
     sc->cam = *cam;
     sc->background = V(background[0], background[1], background[2]);

@@ -195,3 +195,27 @@ def test_png_errors_are_loud(tmp_path):
     # relative paths resolve against the parent of the scene file's directory (the reference: its working directory)
     sc = pt.Scene(scene_path("image_room"), 8, 8)
     assert [t.type for t in sc.textures()] == [3, 3, 0, 1]
+
+
+def test_random_scenes_flatten_like_the_oracle(oracle):
+    # the C++ front end against the oracle-side parser + constructors (themselves bit-identical to the reference on these
+    # scenes, test_oracle_golden.py): matrices, inverses, bounding boxes, BVH order and boxes, lights, materials, textures
+    from scene_gen import random_scene
+
+    for seed in range(24, 64):
+        js = random_scene(seed)
+        osc = oracle.Scene(oracle.sp.load_scene_params(js))
+        sc = pt.Scene(text=json.dumps(js), width=40, height=30)
+        for a, b in zip(sc.instance_tables(), osc.instance_tables()):
+            assert np.array_equal(bits(a), bits(b)), seed
+        on, pn = osc.nodes(), sc.nodes()
+        assert len(on) == len(pn), seed
+        for (b1, l1, r1), (b2, l2, r2) in zip(on, pn):
+            assert (l1, r1) == (l2, r2) and np.array_equal(bits(b1), bits(b2)), seed
+        assert sc.lights() == osc.lights(), seed
+        P, d = osc.params, sc.desc
+        assert d.n_materials == len(P.materials) and d.n_primitives == len(P.prims) and d.n_textures == len(P.textures)
+        for i, m in enumerate(P.materials):
+            dm = d.materials[i]
+            assert (dm.type, dm.texture) == (m.type, m.texture) and tuple(np.float32(x) for x in dm.color) == tuple(m.color), seed
+        assert d.background_texture == P.background_texture and np.array_equal(bits(sc.camera()[:21]), bits(osc.camera(40, 30)[:21]))

@@ -12,6 +12,7 @@ are data (inputs + expected outputs); no reference source is stored.
   F5  hits_<scene>.npy           world->hit of the first 4096 camera rays: hit t p n inst
   F6  ppm_<scene>_64x64x4.ppm    the reference's P6 film output (tonemap + sRGB) for framebuffer fb_<scene>_64x64x4
   F7  perlin_tables.npy          perlin::ranvec (768 floats) + perm_x/y/z (768 values) as the static initialisers left them
+  F9  fb_random_<seed>.npy       framebuffers of 24 seeded random scenes (tests/scene_gen.py) at 40x30x3
   F8  texeval_<scene>.npz        2048 rows (u v px py pz) + every texture's value rgb / alpha there (texture scenes)
 """
 import json
@@ -104,6 +105,19 @@ def main():
             np.save(os.path.join(GOLD, f"hits_{scene}.npy"), po.ref_samples(P, cfg, n, d, mode="hits"))
             manifest["samples"].append({"scene": scene, "file": f"samples_{scene}.npy", "n": n, "config": "200x200x16"})
             manifest["hits"].append({"scene": scene, "file": f"hits_{scene}.npy", "n": n, "config": "200x200x16"})
+        # F9: seeded random scenes (tests/scene_gen.py): arbitrary rotations / scales, spheres, several lights, volumes,
+        # textures, up to 40 instances -- the reference's framebuffer and ray count for each
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from scene_gen import random_scene
+        manifest["random_scenes"] = []
+        for seed in range(24):
+            P = sp.load_scene_params(random_scene(seed))
+            cfg = po.make_config(40, 30, 3, block_w=16, block_h=16)
+            fb, rays = po.ref_render(P, cfg, d)
+            np.save(os.path.join(GOLD, f"fb_random_{seed:02d}.npy"), fb)
+            manifest["random_scenes"].append({"seed": seed, "file": f"fb_random_{seed:02d}.npy", "width": 40, "height": 30,
+                                              "samples": 3, "kwargs": {"block_w": 16, "block_h": 16}, "rays": rays,
+                                              "instances": len(P.instances)})
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("done")
