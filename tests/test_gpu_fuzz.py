@@ -61,3 +61,24 @@ def test_random_scenes_match_the_oracle(oracle):
         assert ((bits(g) == bits(o)) | (g == o)).all(), seed
         for a, b in CTR.items():
             assert gc[a] == oc[b], (seed, a, gc[a], oc[b])
+
+
+def test_large_instance_counts(oracle):
+    # 200 instances (a BVH of ~255 nodes, 8 short-stack slots: the deepest the sweep holds) render bit-exactly; beyond
+    # that pt_create refuses loudly instead of traversing wrongly
+    import json
+    from scene_gen import random_scene
+
+    js = random_scene(7, n_inst=200, volume=False)
+    sc = pt.Scene(text=json.dumps(js), width=24, height=18)
+    r = pt.Renderer(sc, seed=1, light_samples=2)
+    g = r.render(2)
+    gc = r.counters()
+    r.close()
+    osc = oracle.Scene(oracle.sp.load_scene_params(js))
+    o, oc = osc.render_stream(oracle.make_config(24, 18, 2, light_samples=2), seed=1, threads=2)
+    assert ((bits(g) == bits(o)) | (g == o)).all()
+    assert all(gc[a] == oc[b] for a, b in CTR.items())
+    big = pt.Scene(text=json.dumps(random_scene(8, n_inst=300, volume=False)), width=8, height=8)
+    with pytest.raises(pt.PathtraceError, match="short-stack"):
+        pt.Renderer(big)
