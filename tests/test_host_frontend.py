@@ -150,6 +150,21 @@ def test_film_output_matches_reference_ppm(tmp_path, scene):
     assert got == gold, f"{sum(a != b for a, b in zip(got, gold))} of {len(gold)} bytes differ"
 
 
+def test_film_output_matches_reference_ppm_on_random_scenes(tmp_path, manifest):
+    # the same for twelve generated scenes (bright sphere lights, fog, open sky: very different white points)
+    n = 0
+    for e in manifest["random_scenes"]:
+        ppm = os.path.join(GOLD, f"ppm_random_{e['seed']:02d}.ppm")
+        if not os.path.exists(ppm):
+            continue
+        fb = np.load(os.path.join(GOLD, e["file"]))
+        out = tmp_path / "r.ppm"
+        pt.write_ppm(str(out), fb, samples=e["samples"], exposure_field=2.2)
+        assert out.read_bytes() == open(ppm, "rb").read(), e["seed"]
+        n += 1
+    assert n >= 12
+
+
 def test_ppm_writer(tmp_path):
     # film output (renderer.h:24-55): header, size, bottom row written last, white point = max luminance
     fb = np.zeros((4, 6, 3), np.float32)

@@ -113,7 +113,11 @@ def main():
         for seed in range(24):
             P = sp.load_scene_params(random_scene(seed))
             cfg = po.make_config(40, 30, 3, block_w=16, block_h=16)
-            fb, rays = po.ref_render(P, cfg, d)
+            ppm = os.path.join(d, "rnd.ppm") if seed < 12 else None
+            fb, rays = po.ref_render(P, cfg, d, ppm)
+            if ppm:
+                with open(ppm, "rb") as f, open(os.path.join(GOLD, f"ppm_random_{seed:02d}.ppm"), "wb") as g:
+                    g.write(f.read())
             np.save(os.path.join(GOLD, f"fb_random_{seed:02d}.npy"), fb)
             manifest["random_scenes"].append({"seed": seed, "file": f"fb_random_{seed:02d}.npy", "width": 40, "height": 30,
                                               "samples": 3, "kwargs": {"block_w": 16, "block_h": 16}, "rays": rays,
