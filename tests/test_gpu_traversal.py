@@ -101,3 +101,38 @@ def test_world_hit_matches_oracle_on_adversarial_rays(oracle, scene):
             assert np.array_equal(ginst, inst), (nr, k, (ginst != inst).sum())
             assert (same_t(tn[:, k], ot) | (hit == 0)).all(), (nr, k)
     r.close()
+
+
+@pytest.mark.parametrize("seed", [3, 11, 27, 39])
+def test_world_hit_on_random_scenes(oracle, seed):
+    # the same ray set against generated scenes (tests/scene_gen.py): rotated and non-uniformly scaled instances, spheres,
+    # fog, 20-45 BVH nodes; plus rays aimed exactly at instance bounding-box corners
+    import json
+    from scene_gen import random_scene
+
+    js = random_scene(seed)
+    sc = pt.Scene(text=json.dumps(js), width=32, height=32)
+    rng = np.random.default_rng(seed)
+    o, d = adversarial_rays(rng, sc.nodes()[0][0], n_random=20000)
+    _, _, bbox = sc.instance_tables()
+    corners = np.concatenate([bbox[:, [0, 1, 2]], bbox[:, [3, 4, 5]], bbox[:, [0, 4, 2]], bbox[:, [3, 1, 5]]]).astype(np.float64)
+    src = np.array([[278.0, 278.0, -700.0], [100.0, 500.0, 100.0]])
+    for p in src:
+        o = np.concatenate([o, np.repeat(p[None], len(corners), 0).astype(np.float32)])
+        d = np.concatenate([d, (corners - p).astype(np.float32)])
+    r = pt.Renderer(sc, max_paths_in_flight=4096)
+    osc = oracle.Scene(oracle.sp.load_scene_params(js))
+    k0, k1, vd = 0xabcdef1, 0x2468ace, 24
+    t, ids = r.trace_rays(o, d, k0, k1, vd)
+    hit, ot, inst = osc.world_hit_stream(o, d, k0, k1, vd)
+    ginst = np.where(ids >= 0, ids >> 3, -1)
+    assert np.array_equal(ginst, inst), f"{(ginst != inst).sum()} instance mismatches, first at {np.argmax(ginst != inst)}"
+    assert (same_t(t, ot) | (hit == 0)).all()
+    assert (ids >= 0).sum() > 2000
+    nn = (len(o) // 2) * 2
+    t2, id2 = r.trace_rays(o[:nn:2], d[:nn].reshape(-1, 2, 3), k0, k1, vd)
+    for k in range(2):
+        hit, ot, inst = osc.world_hit_stream(o[:nn:2], d[:nn].reshape(-1, 2, 3)[:, k], k0, k1, vd + 16 * k)
+        assert np.array_equal(np.where(id2[:, k] >= 0, id2[:, k] >> 3, -1), inst), k
+        assert (same_t(t2[:, k], ot) | (hit == 0)).all(), k
+    r.close()
