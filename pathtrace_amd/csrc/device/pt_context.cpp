@@ -373,7 +373,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     }
     for (DOp &op : ops)
         if (op.kind == OP_LEAF_VOLBOX) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
-    ops.push_back(DOp{});   // padding: the sweep prefetches the first half of op[pc + 1]
+    ops.push_back(DOp{});   // padding op (never executed)
     // emitted radiance by hit id (instance*8 + face): power * emit->value * emit->alpha (material.h:219), the same two
     // float multiplications the kernels would do (this file is compiled with -ffp-contract=off)
     std::vector<float4> emit((size_t)sc->n_instances * 8, make_float4(0.f, 0.f, 0.f, 0.f));

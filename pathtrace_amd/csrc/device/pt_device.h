@@ -54,7 +54,7 @@ struct DTex {            // 48 bytes
 // COMBINE keeps the reference's rule "both hit: left iff left.t < right.t" (bvh.h:40-47), so exact-t ties and
 // NaN t resolve identically.  Every op carries the data it needs INLINE (node box, or the instance's inverse
 // affine + its primitive's parameters): one op = one 128-byte scalar load with an address that depends only on
-// the program counter, so loads are never chained (op -> instance -> primitive) and can be prefetched.
+// the program counter, so loads are never chained (op -> instance -> primitive).
 enum {
     OP_ENTER = 0,        // f[0..5] = node bbox; a = pc to continue at when the box is missed
     OP_COMBINE = 1,      // slot
@@ -66,7 +66,7 @@ enum {
     OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, f[19] = bits(vol_ord)
 };
 struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in the device array
-    // first half: everything an op needs FIRST (header + node box or instance matrix); it is prefetched one op ahead
+    // first half: everything an op needs FIRST (header + node box or instance matrix)
     int32_t kind;
     int32_t a;           // ENTER: skip target;  LEAF: instance index (hit id = a*8 + face)
     int32_t slot;        // COMBINE: short-stack slot;  LEAF: 1 if the instance's inverse linear part is exactly the identity

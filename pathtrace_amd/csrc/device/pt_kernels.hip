@@ -326,16 +326,15 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
     fin = fin && isfinite(A.x) && isfinite(A.y) && isfinite(A.z);
     const bool all_finite = __all(fin || !lane_valid);   // wave-uniform
     const int n_ops = S.n_ops;
-    // Scalar-load pipeline: an op is two 64-byte halves.  The first half (header + box / matrix) of op pc+1 is
-    // requested while op pc executes; the second half (primitive parameters) of op pc is requested at the top of
-    // its iteration and is only waited for after the ray has been transformed.  Addresses depend on pc alone.
-    i32x16 w0 = *reinterpret_cast<const i32x16 *>(&S.ops[0]);
+    // An op is two 64-byte scalar loads whose addresses depend on pc alone; the second half (primitive parameters) is only
+    // waited for after the ray has been transformed.  Prefetching the next op's first half was tried and removed: carrying
+    // it across the loop edge costs eight s_mov_b64 per op on the scalar unit, more than the latency the other waves hide
+    // anyway (k_extend -32 % without it).
     for (int pc = 0; pc < n_ops; ++pc) {
+        const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc]);
         const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&S.ops[pc]) + 1);
-        const i32x16 nxt = *reinterpret_cast<const i32x16 *>(&S.ops[pc + 1]);   // the array ends with a padding op
         const int kind = w0[0], op_a = w0[1], op_slot = w0[2], op_push = w0[3];
         const int op_id_base = op_a * 8;
-        bool jumped = false;
 #define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
         if (op_push >= 0) {
 #pragma unroll
@@ -375,7 +374,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                 any_in |= (pc >= skip[r]);
             }
             // no ray of the wave is inside this subtree any more: jump to its end -- wave-uniform, one ballot
-            if (!__any(any_in)) { pc = op_a - 1; jumped = true; }
+            if (!__any(any_in)) pc = op_a - 1;
         } else if (kind == OP_COMBINE) {   // bvh.h:36-66: left iff left.hit && (!right.hit || left.t < right.t)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
@@ -465,8 +464,6 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         }
 #undef XF_DIR
 #undef OPF
-        if (jumped) w0 = *reinterpret_cast<const i32x16 *>(&S.ops[pc + 1]);   // rare: the prefetched op is not the next one
-        else w0 = nxt;
     }
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
