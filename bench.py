@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 1920, 1080
+if os.environ.get("PT_BENCH_SIZE"):   # e.g. 3840x2160 for BASELINE config 5's frame; the default is the headline 1080p
+    WIDTH, HEIGHT = (int(v) for v in os.environ["PT_BENCH_SIZE"].lower().split("x"))
 SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
 SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
@@ -263,7 +265,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "scenes/cornell_box.json 1920x1080, iterative NEE path tracing, max_bounces 10, "
+            "config": {"workload": f"scenes/{os.path.basename(args.scene)} {WIDTH}x{HEIGHT}, iterative NEE path tracing, max_bounces 10, "
                                    "light_samples 4, russian roulette, %d spp per step per frame (K=64 at N=1 is 1024 spp)" % spp_step,
                        "spp_total": spp_step * args.steps, "camera_samples": int(total_samples), "rays": int(total_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
