@@ -258,6 +258,15 @@ std::vector<uint8_t> inflate_zlib(const std::vector<uint8_t> &z)
             }
         }
     }
+    {   // zlib trailer: Adler-32 of the inflated bytes (RFC 1950), big-endian after the deflate stream
+        br.align();
+        if (br.pos + 4 > br.n) throw pth::JsonError("PNG: zlib trailer missing");
+        uint32_t a = 1, bsum = 0;
+        for (uint8_t v : out) { a = (a + v) % 65521u; bsum = (bsum + a) % 65521u; }
+        const uint8_t *t = br.p + br.pos;
+        const uint32_t want = ((uint32_t)t[0] << 24) | (t[1] << 16) | (t[2] << 8) | t[3];
+        if (((bsum << 16) | a) != want) throw pth::JsonError("PNG: Adler-32 mismatch in the image data");
+    }
     return out;
 }
 std::string read_file(const std::string &path);
@@ -271,10 +280,20 @@ std::vector<uint8_t> decode_png(const std::string &path, int &width, int &height
     std::vector<uint8_t> idat, plte, trns;
     int depth = 0, ctype = 0, interlace = 0;
     bool have_hdr = false;
+    auto crc32 = [](const uint8_t *p, size_t n) {   // PNG chunk CRC (ISO 3309); lodepng checks it by default
+        uint32_t c = 0xffffffffu;
+        for (size_t i = 0; i < n; i++) {
+            c ^= p[i];
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1u)));
+        }
+        return c ^ 0xffffffffu;
+    };
+    bool ended = false;
     for (size_t pos = 8; pos + 12 <= raw.size();) {
         const uint32_t n = be32(pos);
         const std::string typ(raw, pos + 4, 4);
-        if (pos + 12 + n > raw.size()) throw pth::JsonError("PNG: truncated chunk in " + path);
+        if (pos + 12 + (size_t)n > raw.size()) throw pth::JsonError("PNG: truncated chunk in " + path);
+        if (crc32(b + pos + 4, 4 + (size_t)n) != be32(pos + 8 + n)) throw pth::JsonError("PNG: chunk CRC mismatch in " + path);
         const uint8_t *body = b + pos + 8;
         if (typ == "IHDR" && n >= 13) {
             width = (int)be32(pos + 8); height = (int)be32(pos + 12);
@@ -283,10 +302,11 @@ std::vector<uint8_t> decode_png(const std::string &path, int &width, int &height
         } else if (typ == "PLTE") plte.assign(body, body + n);
         else if (typ == "tRNS") trns.assign(body, body + n);
         else if (typ == "IDAT") idat.insert(idat.end(), body, body + n);
-        else if (typ == "IEND") break;
+        else if (typ == "IEND") { ended = true; break; }
         pos += 12 + n;
     }
     if (!have_hdr || width < 1 || height < 1) throw pth::JsonError("PNG: no IHDR in " + path);
+    if (!ended) throw pth::JsonError("PNG: no IEND chunk in " + path);
     if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6))
         throw pth::JsonError("PNG: only non-interlaced 8-bit images are supported (" + path + ")");
     const int ch = ctype == 0 ? 1 : (ctype == 2 ? 3 : (ctype == 3 ? 1 : (ctype == 4 ? 2 : 4)));
