@@ -2,26 +2,37 @@
 """Headline benchmark: Mrays/s of the per-pixel NEE path-tracing hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no torch.distributed environment, this process starts the N ranks itself as child processes
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`, one per GPU) BEFORE anything here
+touches the GPU, relays rank 0's JSON line and exits with the children's return code; launched under
+torch.distributed.run by someone else it runs as one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment).
 
 Workload (BASELINE.json configs[1]): scenes/cornell_box.json, 1920x1080, max_bounces 10, light_samples 4, russian
-roulette on, normal_offset 1e-4.  One *step* = one wavefront pass over the whole frame at SPP_PER_STEP*N = 16 N samples
-per pixel (one batch of ~33 M camera samples per GPU); the default K = 64 steps at N = 1 is exactly the 1024 spp of
-configs[1].  "ray" = one World::hit query, extension + shadow, the reference's own unit (integrator.h:192,247).
+roulette on, normal_offset 1e-4.  One *step* = one pass of the hot path over the whole frame at 16 samples per pixel
+(33 M camera samples); the default K = 64 steps is exactly the 1024 spp of configs[1].  "ray" = one World::hit query,
+extension + shadow, the reference's own unit (integrator.h:192,247).
 
-N > 1: one process per GPU; the image is partitioned by 128x128 tile in NaiveSpiral order, ownership
-balanced over measured per-tile ray counts (pathtrace_amd/distributed.py; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank
-k mod N), every rank renders its tiles with no communication, and ONE RCCL sum-reduce of the framebuffer to rank 0
-ends the timed region.  Per-GPU work is held fixed as N grows (samples per step scale with N): "weak".
+N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
+partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over measured per-tile ray counts
+(pathtrace_amd/distributed.py; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank k mod N).  Every rank renders ITS tiles for all
+K steps with no communication -- N steps per launch, so that a wavefront batch stays at ~33 M paths -- and ONE RCCL
+sum-reduce of the framebuffer to rank 0 ends the timed region.  PT_BENCH_SCALING=weak keeps per-GPU work fixed instead
+(every step renders 16*N spp).
 
 The timed region holds only GPU work on device-resident data (scene tables + streams live in HBM; there are no host
-buffers on the path).  Rank 0 also reports:
-  roofline      the dominant kernel's algorithmic bytes / its HIP-event time, against 8 TB/s (SURVEY.md 8d byte model)
+buffers on the path) and runs with the library's per-launch event profiling OFF.  The same K steps are then repeated with
+HIP events around every launch (on the stream each kernel is launched on) for the roofline block.  Rank 0 also reports:
+  roofline      dominant kernel: algorithmic bytes / its HIP-event time against 8 TB/s (SURVEY.md 8d byte model), the
+                measured HBM traffic and vector-instruction counts of the same build (rocprofv3 PMC passes, profiles/),
+                and which roof binds
+  configs       short sub-runs of BASELINE configs 3, 4 and config 5's 4K frame on this GPU
   cpu_baseline  the oracle (CPU restatement, stream mode, all host cores) on a bounded sample of the same workload
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,6 +46,9 @@ SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
 SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# vector ALU roof: 256 CUs x 4 SIMDs, one wave64 FP32 mul/add/fma every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
+# v_fma_f32 2 cycles per wave64 = 157.3 TFLOP/s); other vector instruction classes issue at 4 or more cycles
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2
 # SURVEY.md 8(d) byte model, per unit of each kernel
 BYTES_PER_EXT_RAY_EXTEND = 32 + 16          # read ray, write hit
 BYTES_PER_SHADOW_RAY_CONNECT = 48 + 24      # read shadow record, radiance RMW
@@ -46,22 +60,93 @@ def shade_bytes(E, H, S):
     return 96 * E + 48 * H + 48 * S
 
 
+def self_launch(n, argv):
+    """Start the N ranks as fresh child processes (this parent never touches the GPU) and relay their exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def file_derived_profile(dom):
+    """HBM traffic and vector-instruction counts of the dominant kernel from the newest committed rocprofv3 PMC summaries
+    (tools/profile_gpu.sh writes them; they are NOT measured by this run and are labelled with their file)."""
+    import glob
+    out = {"traffic": None, "traffic_source": None, "valu": None}
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), key=os.path.getmtime)
+    if tfiles:
+        try:
+            d = json.load(open(tfiles[-1]))
+            out["traffic"] = d.get(dom, {}).get("hbm_bytes_per_launch")
+            out["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
+        except Exception:
+            pass
+    mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instruction_mix.json")), key=os.path.getmtime)
+    if mixes:
+        try:
+            mk = json.load(open(mixes[-1])).get(dom)
+            if mk:
+                out["valu"] = {"valu_per_wave": mk["valu_per_wave"], "salu_over_valu": mk["salu_over_valu"],
+                               "valu_insts_per_s_profiled": mk["valu_insts_per_s"],
+                               "source": "profiles/" + os.path.basename(mixes[-1])}
+        except Exception:
+            pass
+    return out
+
+
+def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
+    """A short run of another BASELINE configuration on this GPU: Mrays/s (unprofiled), rays per camera sample, dominant kernel."""
+    scene = pt.Scene(os.path.join(ROOT, "scenes", scene_file), w, h)
+    r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=w * h * spp_step)
+    r.render_async(0, spp_step)
+    r.wait()
+    r.clear()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        r.render_async(i * spp_step, (i + 1) * spp_step)
+    r.wait()
+    dt = time.perf_counter() - t0
+    c = r.counters()
+    r.set_profiling(True)
+    for i in range(steps, steps + 2):
+        r.render_async(i * spp_step, (i + 1) * spp_step)
+    r.wait()
+    kt = r.kernel_times()
+    dom = max(("extend", "shade", "connect"), key=lambda k: kt[k]["ms"])
+    r.close()
+    scene.close()
+    return {"config": name, "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp",
+            "value": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
+            "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
+            "dominant_kernel": "k_" + dom,
+            "kernel_ms_profiled_2_steps": {k: round(v["ms"], 3) for k, v in kt.items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true")
     ap.add_argument("--scene", default=SCENE)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = args.gpus
-    if world != n:
-        if world == 1 and n > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        if n > 1:
+            sys.exit(self_launch(n, sys.argv[1:]))   # nothing above this line has touched torch or HIP
+        world, rank, local_rank = 1, 0, 0
+    else:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         n = world
 
     import torch  # device memory for the framebuffer + torch.distributed (RCCL) only
@@ -84,9 +169,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=n, device_id=torch.device("cuda", local_rank))
 
+    weak = os.environ.get("PT_BENCH_SCALING") == "weak"
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
-    spp_step = SPP_PER_STEP * n
     from pathtrace_amd.distributed import measure_tile_costs, reduce_framebuffer, tiles_for_rank
+    setup_t0 = time.perf_counter()
     if n == 1:
         my_tiles = [(0, 0, WIDTH, HEIGHT)]
     else:
@@ -98,15 +184,26 @@ def main():
             costs = measure_tile_costs(planner, pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE))
             planner.close()
         my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
-    # path slots for exactly one step of this rank's pixels: one wavefront batch per step (at N = 1: W*H*16 = 33 M)
+    setup_ms = (time.perf_counter() - setup_t0) * 1e3
+    # One launch = `group` steps of this rank's pixels: a wavefront batch of ~W*H*16 = 33 M paths at every N.
+    #   strong (default): total work fixed -- K steps of 16 spp over the frame; each rank renders its 1/N of the pixels
+    #                     for all K steps, N steps per launch
+    #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
+    group = n
+    spp_launch = SPP_PER_STEP * group
+    total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
-    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_step)
+    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_launch)
     # render straight into a torch tensor so that the final reduce needs no copy
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
-    def step(i):
-        r.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
+    def render_range(s0, s1):
+        s = s0
+        while s < s1:
+            e = min(s + spp_launch, s1)
+            r.render_tiles_async(my_tiles, s, e)
+            s = e
 
     def sync():
         r.wait()
@@ -115,42 +212,52 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def timed_pass():
+        r.clear()
+        sync()
+        t0 = time.perf_counter()
+        render_range(0, total_spp)
+        r.wait()
+        if rehearsal and dist is not None:
+            fb_host = fb.cpu()
+            reduce_framebuffer(fb_host, dst=0)
+            fb.copy_(fb_host)
+        else:
+            reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
+        sync()
+        return time.perf_counter() - t0
+
+    warm_spp = SPP_PER_STEP * args.warmup * (n if weak else 1)
+    if warm_spp:
+        render_range(0, warm_spp)
     sync()
     if dist is not None and not rehearsal and args.warmup > 0:
         reduce_framebuffer(fb, dst=0)   # untimed: RCCL sets its rings and kernels up on the first reduce of this shape
         sync()
-    r.clear()
-    r.set_profiling(True)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    r.wait()
-    if rehearsal and dist is not None:
-        fb_host = fb.cpu()
-        reduce_framebuffer(fb_host, dst=0)
-        fb.copy_(fb_host)
-    else:
-        reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
-    sync()
-    dt = time.perf_counter() - t0
 
+    # ---- the timed region: exactly K steps, per-launch profiling off ----
+    r.set_profiling(False)
+    dt = timed_pass()
     ctr = r.counters()
+    fb_sum = float(fb[..., :3].double().sum().item()) if rank == 0 else 0.0
+    # ---- the same K steps again with HIP events around every launch (roofline block) ----
+    r.set_profiling(True)
+    dt_prof = timed_pass()
     kt = r.kernel_times()
+    r.set_profiling(False)
+
     red_dev = "cpu" if rehearsal else f"cuda:{local_rank}"
     rays = torch.tensor([ctr["rays"], ctr["camera_samples"], ctr["extension_rays"], ctr["extension_hits"],
                          ctr["shadow_rays"]], dtype=torch.float64, device=red_dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt, dt_prof], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays, total_samples, E, H, S = [float(x) for x in rays.tolist()]
-    dt = float(tmax.item())
+    dt, dt_prof = [float(x) for x in tmax.tolist()]
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the render stream) ----
+        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the launching streams) ----
         model_bytes = {
             "extend": BYTES_PER_EXT_RAY_EXTEND * kt["extend"]["units"],
             "connect": BYTES_PER_SHADOW_RAY_CONNECT * kt["connect"]["units"],
@@ -160,59 +267,53 @@ def main():
         launches = max(kt[dom]["launches"], 1)
         avg_ms = kt[dom]["ms"] / launches
         achieved = (model_bytes[dom] / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # the binding resource is the vector ALU, not HBM: share of the one-wide VALU issue rate this kernel sustained in
-        # the serialised counter pass (tools/profile_gpu.sh pass 4 -> profiles/*_instruction_mix.json)
+        fd = file_derived_profile(dom)
+        # HBM roof from the counters: measured bytes per launch (PMC passes of the same build, profiles/) over this run's
+        # own launch duration
+        hbm_meas = None
+        if fd["traffic"]:
+            g = fd["traffic"] / (avg_ms * 1e-3) / 1e9
+            hbm_meas = {"achieved": round(g, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 5),
+                        "bytes_per_launch": fd["traffic"], "source": fd["traffic_source"],
+                        "note": "traffic from the PMC passes of tools/profile_gpu.sh (not measured by this run) / this run's HIP-event launch time"}
+        # vector ALU roof: wave64 vector instructions per second of the dominant kernel against one instruction per SIMD
+        # every 2 cycles; instructions per wave come from the PMC pass of the same build, launch time from this run.
+        # A wave processes 64 units (rays) per chunk pass; instructions per unit = valu_per_wave / (units per wave).
         valu = None
-        try:
-            import glob
-            mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instruction_mix.json")))
-            if mixes:
-                mk = json.load(open(mixes[-1])).get(dom)
-                if mk:
-                    valu = {"valu_issue_fraction": mk["valu_issue_fraction"], "valu_per_wave": mk["valu_per_wave"],
-                            "salu_over_valu": mk["salu_over_valu"], "effective_clock_GHz": mk["effective_clock_GHz"],
-                            "source": "profiles/" + os.path.basename(mixes[-1])}
-        except Exception:
-            valu = None
-        # the same kernel without a second batch sharing the chip: a short extra pass on a single-lane context (the timed
-        # region above runs two batches in flight, which is faster overall but stretches every individual launch)
-        solo = None
-        try:
-            os.environ["PATHTRACE_HIP_LANES"] = "1"
-            r1 = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_step)
-            r1.render_tiles_async(my_tiles, 0, spp_step)
-            r1.wait()
-            r1.set_profiling(True)
-            for i in range(1, 4):
-                r1.render_tiles_async(my_tiles, i * spp_step, (i + 1) * spp_step)
-            r1.wait()
-            k1 = r1.kernel_times()[dom]
-            per_unit = {"extend": BYTES_PER_EXT_RAY_EXTEND, "connect": BYTES_PER_SHADOW_RAY_CONNECT}.get(dom)
-            b1 = per_unit * k1["units"] if per_unit else shade_bytes(*[r1.counters()[x] * 3 / 4 for x in ("extension_rays", "extension_hits", "shadow_rays")])
-            solo_gbs = b1 / (k1["ms"] * 1e-3) / 1e9
-            solo = {"achieved": round(solo_gbs, 2), "frac": round(solo_gbs / HBM_PEAK_GBS, 5),
-                    "avg_launch_ms": round(k1["ms"] / max(k1["launches"], 1), 5), "launches": k1["launches"]}
-            r1.close()
-        except Exception as e:   # the headline number does not depend on this pass
-            solo = {"error": str(e)}
-        finally:
-            os.environ.pop("PATHTRACE_HIP_LANES", None)
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        if fd["valu"]:
+            v = dict(fd["valu"])
+            v["peak_wave_insts_per_s"] = VALU_PEAK_WAVE_INSTS
+            v["achieved_wave_insts_per_s_profiled_pass"] = v.pop("valu_insts_per_s_profiled")
+            v["frac"] = round(v["achieved_wave_insts_per_s_profiled_pass"] / VALU_PEAK_WAVE_INSTS, 4)
+            v["note"] = ("instruction counts from the serialised PMC pass of tools/profile_gpu.sh (not measured by this run); "
+                         "peak = 1024 SIMDs x 2.4 GHz / 2 cycles, the rate of FP32 mul/add/fma only")
+            valu = v
+        hbm_frac = achieved / HBM_PEAK_GBS
+        bound = "hbm"
+        if valu and valu["frac"] > max(hbm_frac, hbm_meas["frac"] if hbm_meas else 0.0):
+            bound = "valu"
+        roofline = {"bound": bound, "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": fd["traffic"],
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "bytes_per_launch_model": round(model_bytes[dom] / launches, 1),
                     "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
-                    "single_batch_in_flight": solo,
+                    "kernel_launches": {k: v["launches"] for k, v in kt.items()},
+                    "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4),
+                    "hbm_measured": hbm_meas,
                     "valu": valu,
                     "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
                     "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)}
+
+        configs = None
+        if n == 1 and not args.no_configs and not os.environ.get("PT_BENCH_SIZE"):
+            configs = []
+            for name, sf, w, h, spp, st in (("configs[2]", "cornell_box_small_lights.json", 1920, 1080, 16, 4),
+                                            ("configs[3]", "cornell_box_with_volume.json", 1920, 1080, 16, 4),
+                                            ("configs[4] frame, 1 GPU", "cornell_box.json", 3840, 2160, 4, 4)):
+                try:
+                    configs.append(sub_config(pt, name, sf, w, h, spp, st, local_rank))
+                except Exception as e:   # the headline number does not depend on these
+                    configs.append({"config": name, "error": str(e)})
 
         cpu = None
         parity = None
@@ -240,9 +341,10 @@ def main():
                                                "sample": f"cornell_box 200x200x16 ({mctr['rays']} rays), oracle mt19937 mode, "
                                                          f"{mdt:.2f} s wall"}}
             if n == 1:
-                # parity reported with the metric, at the bench's full frame size: the same 4 spp on the
+                # parity reported with the metric, at the bench's full frame size: the same 64 spp on the
                 # GPU must be the oracle's framebuffer bit for bit, with equal path counters
                 import numpy as np
+                r.set_device_framebuffer(None, 0)
                 r.clear()
                 r.render_async(0, spp_cpu)
                 gfb = r.framebuffer()
@@ -256,25 +358,27 @@ def main():
                               ("term_emitter", "term_emitter"), ("term_pdf", "term_pdf"),
                               ("term_bounce_limit", "term_bounce_limit")))}
 
-        if rehearsal:
-            img = fb.cpu().numpy()[..., :3]
-            print(json.dumps({"rehearsal_fb_sum": float(img.astype("float64").sum()), "spp_total": spp_step * args.steps,
-                              "nonzero_pixels": int((img.sum(axis=2) != 0).sum())}), file=sys.stderr, flush=True)
+        knobs = {k: v for k, v in os.environ.items() if k.startswith("PATHTRACE_HIP_") or k.startswith("PT_BENCH_")}
         out = {
             "metric": "Mrays/sec + achieved HBM GB/s %peak, cornell_box 1080p@1024spp, 1/2/4/8 GPU",
             "value": round(total_rays / dt / 1e6, 2),
             "unit": "Mrays/s",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scenes/{os.path.basename(args.scene)} {WIDTH}x{HEIGHT}, iterative NEE path tracing, max_bounces 10, "
-                                   "light_samples 4, russian roulette, %d spp per step per frame (K=64 at N=1 is 1024 spp)" % spp_step,
-                       "spp_total": spp_step * args.steps, "camera_samples": int(total_samples), "rays": int(total_rays),
+                                   f"light_samples 4, russian roulette; step = {SPP_PER_STEP} spp over the frame"
+                                   + (f" x {n} (weak)" if weak else "") + f" (K=64 is 1024 spp), {spp_launch} spp per launch per rank",
+                       "spp_total": total_spp, "camera_samples": int(total_samples), "rays": int(total_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
-                       "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce")},
+                       "framebuffer_sum": fb_sum,
+                       "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce"),
+                       "partition_setup_ms": round(setup_ms, 1),
+                       "knobs": knobs},
             "roofline": roofline,
+            "configs": configs,
             "cpu_baseline": cpu,
             "parity": parity,
         }

@@ -317,7 +317,7 @@ def _cfg_args(cfg: Config):
 
 
 def ref_run(params: sp.SceneParams, mode: str, args, workdir: str):
-    """Run oracle/_ref/ref_driver (build container only; the binary also travels to the GPU box)."""
+    """Run oracle/_ref/ref_driver (build container only: oracle/_ref/ is git-ignored and gpurun-ignored, nothing on the GPU box runs it)."""
     ppath = os.path.join(workdir, "scene.params")
     with open(ppath, "w") as f:
         f.write(sp.to_text(params))

@@ -37,17 +37,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, defs=(), out: str = None) -> str:
+    """`defs` / `out`: an A/B variant with extra -D flags under another file name (loaded through PATHTRACE_HIP_LIB)."""
+    if out is None and not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + SOURCES + ["-o", LIB]
+    target = os.path.join(LIB_DIR, out) if out else LIB
+    cmd = [HIPCC] + FLAGS + list(defs) + SOURCES + ["-o", target]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    # python -m pathtrace_amd.build [--force] [--variant NAME -DFOO ...]  ->  lib/libpathtrace_hip_NAME.so
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build(force=True, verbose=True, defs=[a for a in sys.argv[i + 2:]], out=f"libpathtrace_hip_{sys.argv[i + 1]}.so"))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

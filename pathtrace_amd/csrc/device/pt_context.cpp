@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -156,10 +157,18 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
         op.push_slot = pending_push;
         pending_push = -1;
         memcpy(op.f, in.inv, 12 * sizeof(float));
-        {   // linear part exactly the identity (pure translation): the sweep then adds the translation and skips 30 multiplies
+        {   // shape of the inverse's linear part (pt_device.h DOp::slot): 1 = exactly the identity (pure translation: the
+            // sweep adds the translation and skips 30 multiplies); 2 / 3 / 4 = the x / y / z axis is mapped to itself
+            // (row and column of that axis zero off the diagonal: a rotation about one axis, with any scaling)
             const float *m = in.inv;
-            op.slot = (m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f &&
-                       m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f) ? 1 : 0;
+            const bool zx = m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[8] == 0.0f;
+            const bool zy = m[4] == 0.0f && m[6] == 0.0f && m[1] == 0.0f && m[9] == 0.0f;
+            const bool zz = m[8] == 0.0f && m[9] == 0.0f && m[2] == 0.0f && m[6] == 0.0f;
+            if (zx && zy && zz && m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f) op.slot = 1;
+            else if (zx) op.slot = 2;
+            else if (zy) op.slot = 3;
+            else if (zz) op.slot = 4;
+            else op.slot = 0;
         }
         switch (p.type) {
         case PT_PRIM_RECT:
@@ -373,7 +382,25 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     }
     for (DOp &op : ops)
         if (op.kind == OP_LEAF_VOLBOX) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
+    if (ops.size() >= (1u << 22)) { set_err("pt_create: traversal program too long (%zu ops)", ops.size()); return -1; }
     ops.push_back(DOp{});   // padding op (never executed)
+    // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
+    // needs neither them nor the pushes), ENTER's skip target re-indexed; stored behind the general program
+    const int n_general = (int)ops.size() - 1;
+    std::vector<int> fast_index(n_general + 1, 0);
+    for (int i = 0, k = 0; i <= n_general; i++) { fast_index[i] = k; if (i < n_general && ops[i].kind != OP_COMBINE) k++; }
+    const int n_fast = fast_index[n_general];
+    for (int i = 0; i < n_general; i++) {
+        if (ops[i].kind == OP_COMBINE) continue;
+        DOp f = ops[i];
+        {   // the fast sweep compares positions as floats: its own index rides in push_slot (unused there), ENTER's target in f[6]
+            const float self = (float)fast_index[i];
+            memcpy(&f.push_slot, &self, 4);
+        }
+        if (f.kind == OP_ENTER) { f.a = fast_index[ops[i].a]; f.f[6] = (float)f.a; }
+        ops.push_back(f);
+    }
+    ops.push_back(DOp{});   // padding
     // emitted radiance by hit id (instance*8 + face): power * emit->value * emit->alpha (material.h:219), the same two
     // float multiplications the kernels would do (this file is compiled with -ffp-contract=off)
     std::vector<float4> emit((size_t)sc->n_instances * 8, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -403,13 +430,37 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
     S.geom_all = 0;
     for (const DOp &op : ops) S.geom_all |= (op.kind == OP_LEAF_SPHERE || op.kind == OP_LEAF_VOLBOX);
+    {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_n): every leaf's linear part is
+        // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
+        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  Scenes outside it (or
+        // PATHTRACE_HIP_NO_FASTDIV=1, an A/B measurement knob) run the IEEE sweep.
+        auto in_range = [](float x, int lo, int hi) {
+            uint32_t u;
+            memcpy(&u, &x, 4);
+            u &= 0x7fffffffu;
+            return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
+        };
+        S.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
+        for (int oi = 0; oi < n_general; oi++) {
+            const DOp &op = ops[oi];
+            if (op.kind == OP_ENTER) {   // world_hit_fast takes min / max of the slab products: the box must be ordered and finite
+                for (int i = 0; i < 3; i++) S.tame &= (op.f[i] <= op.f[i + 3] && std::isfinite(op.f[i]) && std::isfinite(op.f[i + 3])) ? 1 : 0;
+                continue;
+            }
+            if (op.kind < OP_LEAF_RECT_XY) continue;
+            for (int i = 0; i < 12; i++) S.tame &= in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13) ? 1 : 0;
+            const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : 6;   // rect x0 z0 x1 z1 y; box / volume p0 p1; sphere: IEEE divisions
+            for (int i = 0; i < np; i++) S.tame &= in_range(op.g[i], -20, 20) ? 1 : 0;
+        }
+    }
     S.textured = S.bg_tex >= 0;
     for (const DMat &m : mats) S.textured |= m.tex >= 0;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
         dev_upload(c, &S.ops, ops) || dev_upload(c, &S.lights, lights))
         return -1;
     S.n_insts = (int)insts.size(); S.n_prims = (int)prims.size(); S.n_mats = (int)mats.size();
-    S.n_ops = (int)ops.size() - 1; S.n_lights = (int)lights.size(); S.n_vol = nvol;
+    S.n_ops = n_general; S.ops_fast_off = n_general + 1; S.n_ops_fast = n_fast;
+    S.n_lights = (int)lights.size(); S.n_vol = nvol;
     S.stack_depth = std::max(max_depth, 1);
     const pt_camera &cm = sc->camera;
     memcpy(S.cam.origin, cm.origin, 12); memcpy(S.cam.llc, cm.lower_left_corner, 12);

@@ -69,7 +69,8 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
     // first half: everything an op needs FIRST (header + node box or instance matrix)
     int32_t kind;
     int32_t a;           // ENTER: skip target;  LEAF: instance index (hit id = a*8 + face)
-    int32_t slot;        // COMBINE: short-stack slot;  LEAF: 1 if the instance's inverse linear part is exactly the identity
+    int32_t slot;        // COMBINE: short-stack slot;  LEAF: shape of the inverse's linear part -- 0 general, 1 exactly the
+                         // identity, 2 / 3 / 4 the x / y / z axis is mapped to itself (zero row and column off the diagonal)
     int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
     float f[12];
     // second half: primitive parameters, needed only after the ray has been transformed
@@ -100,6 +101,9 @@ struct DScene {
     int32_t textured;            // some material or the background uses the texture table: launch the <TEX = true> kernels
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
     int32_t stack_depth;         // short-stack slots the program uses
+    int32_t ops_fast_off, n_ops_fast;   // the fast program (no COMBINE ops) sits at ops + ops_fast_off
+    int32_t tame;                // every matrix entry / bound of the program's leaves is zero or within [2^-20, 2^20]: the
+                                 // sweep may use the unscaled exact division of pt_fdiv.h (pt_kernels.hip world_hit)
     DCamera cam;
     float bg[3];
     // config

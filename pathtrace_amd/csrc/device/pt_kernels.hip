@@ -27,6 +27,7 @@
 #include <stdlib.h>
 
 #include "pt_device.h"
+#include "pt_fdiv.h"
 
 namespace ptd {
 
@@ -291,6 +292,40 @@ DEVI void box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t
     face = f;
 }
 
+// ---- the same two leaf tests for the FAST sweep (world_hit_fast): every operand is finite and inside the precondition
+// of pt_fdiv.h, so the quotient is fdiv_q -- the bits of num / dpl -- over r = fdiv_rcp(dpl), one refined reciprocal
+// shared by the numerators over one denominator.
+template <int PLANE>
+DEVI float rect_excess_fast(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float t0, float t1, float r, float &t_out)
+{
+    float dx, dpl, dz;
+    rect_axes<PLANE>(Bl, dx, dpl, dz);
+    const float t = fdiv_q(num, dpl, r);
+    const float xh = ox + t * dx;
+    const float zh = oz + t * dz;
+    t_out = t;
+    const float et = fmaxf(t0 - t, t - t1);
+    const float ex = fmaxf(x0 - xh, xh - x1), ez = fmaxf(z0 - zh, zh - z1);
+    return fmaxf(et, fmaxf(ex, ez));
+}
+DEVI void box_hit_fast(const float *p0, const float *p1, v3 Al, v3 Bl, float t0, float t1, float &t_out, int &face)
+{
+    float closest = t1, t;
+    int f = -1;
+    bool h;
+    const float rz = fdiv_rcp(Bl.z);   // the two sides of an axis divide by the same local direction component
+    h = !(rect_excess_fast<0>(p0[0], p0[1], p1[0], p1[1], p0[2] - Al.z, Al.x, Al.y, Bl, t0, closest, rz, t) > 0.0f); closest = h ? t : closest; f = h ? 0 : f;
+    h = !(rect_excess_fast<0>(p0[0], p0[1], p1[0], p1[1], p1[2] - Al.z, Al.x, Al.y, Bl, t0, closest, rz, t) > 0.0f); closest = h ? t : closest; f = h ? 1 : f;
+    const float rx = fdiv_rcp(Bl.x);
+    h = !(rect_excess_fast<2>(p0[1], p0[2], p1[1], p1[2], p0[0] - Al.x, Al.y, Al.z, Bl, t0, closest, rx, t) > 0.0f); closest = h ? t : closest; f = h ? 2 : f;
+    h = !(rect_excess_fast<2>(p0[1], p0[2], p1[1], p1[2], p1[0] - Al.x, Al.y, Al.z, Bl, t0, closest, rx, t) > 0.0f); closest = h ? t : closest; f = h ? 3 : f;
+    const float ry = fdiv_rcp(Bl.y);
+    h = !(rect_excess_fast<1>(p0[0], p0[2], p1[0], p1[2], p0[1] - Al.y, Al.x, Al.z, Bl, t0, closest, ry, t) > 0.0f); closest = h ? t : closest; f = h ? 4 : f;
+    h = !(rect_excess_fast<1>(p0[0], p0[2], p1[0], p1[2], p1[1] - Al.y, Al.x, Al.z, Bl, t0, closest, ry, t) > 0.0f); closest = h ? t : closest; f = h ? 5 : f;
+    t_out = closest;
+    face = f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep over NR rays per lane
 // that share the origin A.  Returns per ray id = -1 (miss) or instance*8 + face, and t.  `stk` points at this
@@ -304,10 +339,14 @@ DEVI void box_hit_shared(const float *p0, const float *p1, v3 Al, v3 Bl, float t
 // ------------------------------------------------------------------------------------------------
 // GA ("all geometry"): the scene has sphere or constant_medium leaves.  Scenes of rects and boxes only (all BASELINE
 // Cornell boxes but the volume one) run the GA = false instantiations, which carry neither the code nor the registers of
-// those leaves (k_extend 56 -> 43 VGPRs, k_connect<2> 79 -> 70).
+// those leaves.
+//
+// This is the GENERAL sweep: IEEE divisions, the tree of COMBINEs on the LDS short stack (NaN t and exact-t ties resolve
+// by the tree's shape like bvh_node::hit), finite or non-finite operands.  Waves whose rays are all tame take
+// world_hit_fast below instead (world_hit picks).
 template <int NR, bool GA>
 DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
-                      const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR])
+                      const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR], bool all_finite)
 {
     const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
     v3 inv[NR];
@@ -320,11 +359,6 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         cur_id[r] = -1;
         skip[r] = lane_valid ? 0 : 0x7fffffff;
     }
-    bool fin = true;
-#pragma unroll
-    for (int r = 0; r < NR; r++) fin = fin && isfinite(B[r].x) && isfinite(B[r].y) && isfinite(B[r].z);
-    fin = fin && isfinite(A.x) && isfinite(A.y) && isfinite(A.z);
-    const bool all_finite = __all(fin || !lane_valid);   // wave-uniform
     const int n_ops = S.n_ops;
     // An op is two 64-byte scalar loads whose addresses depend on pc alone; the second half (primitive parameters) is only
     // waited for after the ray has been transformed.  Prefetching the next op's first half was tried and removed: carrying
@@ -343,32 +377,30 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         if (kind == OP_ENTER) {
             // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays.
             // "t0 > tmin ? t0 : tmin" keeps tmin when t0 is NaN = fmaxf(tmin, t0); likewise fminf for tmax; they are never
-            // NaN themselves, and tmin >= 0.001, tmax <= FLT_MAX rule out inf - inf, so "tmax <= tmin" <=> tmin - tmax >= 0.
+            // NaN themselves.  The reference returns false as soon as tmax <= tmin after an axis; tmin only grows and tmax
+            // only shrinks from axis to axis, so that is the case iff it holds after the last axis.
             const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
             const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
             bool any_in = false;
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                float tmin = T_MIN, tmax = T_MAX, e;
+                float tmin = T_MIN, tmax = T_MAX;
                 {
                     const float a = dx0 * inv[r].x, c = dx1 * inv[r].x;
                     const bool neg = inv[r].x < 0.0f;
                     tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
-                    e = tmin - tmax;
                 }
                 {
                     const float a = dy0 * inv[r].y, c = dy1 * inv[r].y;
                     const bool neg = inv[r].y < 0.0f;
                     tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
-                    e = fmaxf(e, tmin - tmax);
                 }
                 {
                     const float a = dz0 * inv[r].z, c = dz1 * inv[r].z;
                     const bool neg = inv[r].z < 0.0f;
                     tmin = fmaxf(tmin, neg ? c : a); tmax = fminf(tmax, neg ? a : c);
-                    e = fmaxf(e, tmin - tmax);
                 }
-                const bool miss = e >= 0.0f;
+                const bool miss = tmax <= tmin;
                 cur_id[r] = miss ? -1 : cur_id[r];            // masked rays already hold -1
                 skip[r] = max(skip[r], miss ? op_a : 0);      // masked rays: skip >= op_a already
                 any_in |= (pc >= skip[r]);
@@ -393,7 +425,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             // (1*x + 0*y) + 0*z == x; only the sign of a zero component can differ, which no comparison below can see
             // (+-inf t is rejected either way, 0/0 is NaN either way).  A wave holding any non-finite ray (0*inf = NaN
             // would spread across components) takes the general path.
-            const bool ident = (op_slot != 0) && all_finite;
+            const bool ident = (op_slot == 1) && all_finite;
             const v3 Al = ident ? V(m[3] + A.x, m[7] + A.y, m[11] + A.z) : xf_point(m, A);
 #define XF_DIR(b) (ident ? (b) : xf_linear(m, (b)))
             if (kind <= OP_LEAF_RECT_YZ) {   // the three rect alignments first: the most frequent leaf (rect::hit primitive.h:186-225)
@@ -467,6 +499,222 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
     }
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = cur_t[r]; out_id[r] = cur_id[r]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The FAST sweep: the same World::hit for waves whose rays are all TAME (world_hit checks): every component of A and of
+// the B[r] is finite, the B components are non-zero and within [2^-20, 2^20], the A components zero or within
+// [2^-20, 2^20], and the program's leaf data are in the ranges DScene::tame stands for (linear part zero or
+// [2^-44, 2^13] per entry, translation zero or [2^-44, 2^20], bounds zero or [2^-20, 2^20]; checked on the host).
+// It returns the same (t, id) as world_hit_n bit for bit, with fewer instructions:
+//
+//  * Divisions are the unscaled exact sequence of pt_fdiv.h.  Precondition, by the ulp argument (a sum or difference of
+//    floats that are zero or at least m in magnitude is zero or at least ulp(m)): a product m*x is zero or within
+//    [2^-64, 2^33]; a local direction component (m0 x + m1 y) + m2 z is zero or within [2^-87, 2^35]; a local origin
+//    component t + (..) zero or within [2^-87, 2^36]; a numerator plane - o zero or within [2^-87, 2^37]; so every
+//    quotient is zero or within [2^-122, 2^124] and no residual underflows (|n| >= 2^-101).
+//  * Node boxes (aabb::hit): with every B component finite and non-zero no slab product is NaN (0 * inf cannot occur),
+//    so the reference's "swap if invD < 0" is min / max of the two products (multiplication by one finite inv is
+//    monotone under rounding and node boxes are ordered, min <= max), and "tmax <= tmin after some axis" is the test
+//    after the last axis (tmin only grows, tmax only shrinks).
+//  * Transforms: DOp::slot = 2 / 3 / 4 marks an inverse whose linear part maps the x / y / z axis to itself (row and
+//    column of that axis zero off the diagonal: every rotation about one axis, with any scaling) -- the products by
+//    those exact zeros are skipped; for finite operands that changes at most the sign of a zero, which no comparison
+//    of a leaf can see (the argument of the pure-translation shortcut, slot = 1).
+//  * The tree of COMBINEs is a left fold over the leaves in program order: "left iff left.hit && (!right.hit ||
+//    left.t < right.t)" is associative as long as every accepted t is ordered (closest hit, the later leaf on equal t),
+//    so the short stack in LDS and the COMBINE ops are not needed.  A leaf accepted with a NaN t (0 / 0: a ray inside the
+//    plane of a rect through its origin) makes the result depend on the tree's shape: the lane reports it (return
+//    value) and the wave repeats the query with world_hit_n.
+// ------------------------------------------------------------------------------------------------
+template <int AXIS>
+DEVI v3 xf_axis_linear(const float *m, v3 v)
+{   // the axis component is mapped to itself; the other two mix
+    if (AXIS == 0) return V(m[0] * v.x, m[5] * v.y + m[6] * v.z, m[9] * v.y + m[10] * v.z);
+    if (AXIS == 1) return V(m[0] * v.x + m[2] * v.z, m[5] * v.y, m[8] * v.x + m[10] * v.z);
+    return V(m[0] * v.x + m[1] * v.y, m[4] * v.x + m[5] * v.y, m[10] * v.z);
+}
+// local origin and the NR local directions for the shape `pat` of the inverse (one scalar branch chain per op)
+template <int NR>
+DEVI void xf_pat(int pat, const float *m, v3 A, const v3 (&B)[NR], v3 &Al, v3 (&Bl)[NR])
+{
+    if (pat == 1) {
+        Al = V(m[3] + A.x, m[7] + A.y, m[11] + A.z);
+#pragma unroll
+        for (int r = 0; r < NR; r++) Bl[r] = B[r];
+    } else if (pat == 2) {
+        const v3 l = xf_axis_linear<0>(m, A);
+        Al = V(m[3] + l.x, m[7] + l.y, m[11] + l.z);
+#pragma unroll
+        for (int r = 0; r < NR; r++) Bl[r] = xf_axis_linear<0>(m, B[r]);
+    } else if (pat == 3) {
+        const v3 l = xf_axis_linear<1>(m, A);
+        Al = V(m[3] + l.x, m[7] + l.y, m[11] + l.z);
+#pragma unroll
+        for (int r = 0; r < NR; r++) Bl[r] = xf_axis_linear<1>(m, B[r]);
+    } else if (pat == 4) {
+        const v3 l = xf_axis_linear<2>(m, A);
+        Al = V(m[3] + l.x, m[7] + l.y, m[11] + l.z);
+#pragma unroll
+        for (int r = 0; r < NR; r++) Bl[r] = xf_axis_linear<2>(m, B[r]);
+    } else {
+        Al = xf_point(m, A);
+#pragma unroll
+        for (int r = 0; r < NR; r++) Bl[r] = xf_linear(m, B[r]);
+    }
+}
+// The fast program (DScene::ops + ops_fast_off .. + n_ops_fast): the same op list without the COMBINE ops, ENTER's `a`
+// re-targeted.  All per-lane decisions stay in the vector unit (see the note on the scalar unit above): the state of a
+// ray is (cur_t, cur_id, skipf) with cur_t = FLT_MAX while nothing is hit -- a first hit has t <= FLT_MAX and replaces
+// it like the tie rule does -- and a leaf's verdict is the sign of ONE maximum:
+//     take  <=>  !( max3(excess, t - cur_t, skipf - pc) > 0 )
+// excess > 0: the leaf rejects the ray; t - cur_t > 0: the current hit is strictly closer (NaN when t is NaN: ignored,
+// like the reference's "left.t < right.t" is false); skipf - pc > 0: the ray is masked until op skipf.
+// `chk` turns NaN for good as soon as an accepted t is NaN (0 * NaN), which is what the lane reports.
+template <int NR, bool GA>
+DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
+                         const uint32_t (&vol_dim_base)[NR], float (&out_t)[NR], int (&out_id)[NR])
+{
+    const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
+    v3 inv[NR];
+    float cur_t[NR], skipf[NR], chk = 0.0f;
+    int cur_id[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        inv[r] = V(fdiv(1.0f, B[r].x), fdiv(1.0f, B[r].y), fdiv(1.0f, B[r].z));   // aabb.h:38
+        cur_t[r] = FLT_MAX;
+        cur_id[r] = -1;
+        skipf[r] = lane_valid ? 0.0f : 1e9f;
+    }
+    const DOp *__restrict__ prog = S.ops + S.ops_fast_off;
+    const int n_ops = S.n_ops_fast;
+    for (int pc = 0; pc < n_ops; ++pc) {
+        const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&prog[pc]);
+        const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&prog[pc]) + 1);
+        const int kind = w0[0], op_a = w0[1], pat = w0[2];
+        const int op_id_base = op_a * 8;
+        const float pcf = __int_as_float(w0[3]);   // (float)pc, stored by the host (pt_context.cpp)
+#define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
+        if (kind == OP_ENTER) {
+            const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
+            const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
+            const float endf = OPF(6);             // (float)op_a
+            float in_max = 1.0f;   // min over the rays of (skipf - pc): <= 0 iff some ray is still inside
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float ax = dx0 * inv[r].x, cx = dx1 * inv[r].x;
+                const float ay = dy0 * inv[r].y, cy = dy1 * inv[r].y;
+                const float az = dz0 * inv[r].z, cz = dz1 * inv[r].z;
+                const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
+                const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
+                skipf[r] = fmaxf(skipf[r], (tmax <= tmin) ? endf : 0.0f);
+                in_max = fminf(in_max, skipf[r] - pcf);
+            }
+            if (!__any(in_max <= 0.0f)) pc = op_a - 1;   // no ray of the wave is inside this subtree: jump to its end
+            continue;
+        }
+        const float m[12] = {OPF(0), OPF(1), OPF(2), OPF(3), OPF(4), OPF(5), OPF(6), OPF(7), OPF(8), OPF(9), OPF(10), OPF(11)};
+        const float q0[3] = {OPF(12), OPF(13), OPF(14)}, q1[3] = {OPF(15), OPF(16), OPF(17)};
+        v3 Al, Bl[NR];
+        xf_pat<NR>(pat, m, A, B, Al, Bl);
+#define FOLD(r, e_, t_, id_)                                                                              \
+        {                                                                                                 \
+            const bool take_ = !(fmaxf(fmaxf((e_), (t_) - cur_t[r]), skipf[r] - pcf) > 0.0f);             \
+            cur_t[r] = take_ ? (t_) : cur_t[r];                                                           \
+            cur_id[r] = take_ ? (id_) : cur_id[r];                                                        \
+            chk = __builtin_fmaf(0.0f, cur_t[r], chk);                                                    \
+        }
+        if (kind <= OP_LEAF_RECT_YZ) {
+            // one of three bodies per wave (kind is wave-uniform).  The empty volatile asm keeps hipcc from if-converting the
+            // three into "compute all three quotients, select by kind" -- it did: 85 instead of 33 vector instructions
+            float t[NR], e[NR];
+#define RECT_BODY(PLANE, DPL)                                                                                              \
+            {                                                                                                                \
+                float ox, opl, oz;                                                                                           \
+                rect_axes<PLANE>(Al, ox, opl, oz);                                                                           \
+                const float num = q1[1] - opl;                                                                               \
+                _Pragma("unroll") for (int r = 0; r < NR; r++)                                                               \
+                    e[r] = rect_excess_fast<PLANE>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl[r], T_MIN, T_MAX, fdiv_rcp(Bl[r].DPL), t[r]); \
+            }
+            if (kind == OP_LEAF_RECT_XY) { asm volatile("; rect xy"); RECT_BODY(0, z) }
+            else if (kind == OP_LEAF_RECT_YZ) { asm volatile("; rect yz"); RECT_BODY(2, x) }
+            else { asm volatile("; rect xz"); RECT_BODY(1, y) }
+#undef RECT_BODY
+#pragma unroll
+            for (int r = 0; r < NR; r++) FOLD(r, e[r], t[r], op_id_base)
+        } else if (kind == OP_LEAF_BOX) {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float t;
+                int face;
+                box_hit_fast(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
+                FOLD(r, (face >= 0) ? 0.0f : 1.0f, t, op_id_base + face)
+            }
+        } else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float t1v, t2v;
+                int f1, f2;
+                box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
+                box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                bool hit = (f1 >= 0) && (f2 >= 0);
+                chk = __builtin_fmaf(0.0f, t1v, chk);   // a NaN boundary t: let the general sweep decide
+                chk = __builtin_fmaf(0.0f, t2v, chk);
+                t1v = (t1v < T_MIN) ? T_MIN : t1v;
+                t2v = (t2v > T_MAX) ? T_MAX : t2v;
+                hit = hit && !(t1v >= t2v);
+                t1v = (t1v < 0) ? 0.0f : t1v;
+                const float dlen = vlen(Bl[r]);
+                const float distance_inside = (t2v - t1v) * dlen;
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
+                const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
+                hit = hit && (hit_distance < distance_inside);
+                const float tv = t1v + hit_distance / dlen;
+                FOLD(r, hit ? 0.0f : 1.0f, tv, op_id_base)
+            }
+        } else if (GA && kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95 (IEEE divisions: a = |Bl|^2 may leave the precondition)
+            const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+            const float c = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float a = vdot(Bl[r], Bl[r]);
+                const float b = vdot(oc, Bl[r]);
+                const float disc = b * b - a * c;
+                const float ta = (-b - sqrtf(disc)) / a, tb = (-b + sqrtf(disc)) / a;
+                const bool ha = (ta < T_MAX) && (ta > T_MIN), hb = (tb < T_MAX) && (tb > T_MIN);
+                const float ts = ha ? ta : tb;
+                FOLD(r, ((disc > 0) && (ha || hb)) ? 0.0f : 1.0f, ts, op_id_base)
+            }
+        }
+#undef FOLD
+#undef OPF
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) { out_t[r] = (cur_id[r] >= 0) ? cur_t[r] : 0.0f; out_id[r] = cur_id[r]; }
+    return is_nanf(chk);
+}
+
+// World::hit for NR rays of one origin: picks the sweep for this wave (wave-uniform, one scalar branch).
+template <int NR, bool GA>
+DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
+                    const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR])
+{
+    // tame: A components zero or 2^-20 <= |x| <= 2^20, B components 2^-20 <= |x| <= 2^20 (non-zero); implies finite
+    bool tame = fdiv_in_range(A.x, -20, 20) && fdiv_in_range(A.y, -20, 20) && fdiv_in_range(A.z, -20, 20);
+    bool fin = isfinite(A.x) && isfinite(A.y) && isfinite(A.z);
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        tame = tame && fdiv_in_range_nz(B[r].x, -20, 20) && fdiv_in_range_nz(B[r].y, -20, 20) && fdiv_in_range_nz(B[r].z, -20, 20);
+        fin = fin && isfinite(B[r].x) && isfinite(B[r].y) && isfinite(B[r].z);
+    }
+    bool general = true;
+    if (S.tame && __all(tame || !lane_valid)) {
+        general = __any(world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id) && lane_valid);
+#ifdef PT_DBG_NO_REDO
+        general = false;
+#endif
+    }
+    if (general) world_hit_n<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, stk, out_t, out_id, __all(fin || !lane_valid));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -883,7 +1131,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
-        world_hit_n<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
+        world_hit<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0 && n_rays) {
@@ -1147,7 +1395,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
 template <int NR, bool TEX, bool GA>
-__global__ __launch_bounds__(PT_BLOCK, GA ? 6 : 7) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
@@ -1196,7 +1444,7 @@ __global__ __launch_bounds__(PT_BLOCK, GA ? 6 : 7) void k_connect(DScene S, cons
                     coef[k] = V(d.w, e.x, e.y);
                     vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
                 }
-                world_hit_n<R, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit<R, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
@@ -1210,7 +1458,7 @@ __global__ __launch_bounds__(PT_BLOCK, GA ? 6 : 7) void k_connect(DScene S, cons
                 const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
                 float t[1];
                 int id[1];
-                world_hit_n<1, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit<1, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
                 if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
@@ -1272,7 +1520,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
         B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
         vd[r] = vol_dim + (uint32_t)r * 16u;
     }
-    world_hit_n<NR, GA>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
+    world_hit<NR, GA>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
     if (valid) {
 #pragma unroll
         for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }

@@ -136,3 +136,112 @@ def test_world_hit_on_random_scenes(oracle, seed):
         assert np.array_equal(np.where(id2[:, k] >= 0, id2[:, k] >> 3, -1), inst), k
         assert (same_t(t2[:, k], ot) | (hit == 0)).all(), k
     r.close()
+
+
+def _tame(a):
+    """zero or 2^-20 <= |x| <= 2^20 (origins) -- the device's precondition for the fast sweep (pt_kernels.hip world_hit)"""
+    a = np.abs(a)
+    return (a == 0) | ((a >= 2.0 ** -20) & (a <= 2.0 ** 20))
+
+
+def tame_rays(rng, sc, n_random=40000):
+    """Rays that every lane of every wave sends down the FAST sweep (world_hit_fast: unscaled exact division, min/max
+    slabs, axis-shaped transforms, fold instead of the COMBINE tree): finite, non-zero direction components within
+    [2^-20, 2^20].  Aimed at random points, at the corners and edge midpoints of every rect / box face in world space
+    (and a few ulps around them: exact-edge decisions, ties between adjacent leaves), along box edges, from origins on
+    surfaces, inside and outside the scene."""
+    F = np.float32
+    fwd, inv, bbox = sc.instance_tables()
+    d_ = sc.desc
+    targets = []
+    for i in range(d_.n_instances):
+        pr = d_.primitives[d_.instances[i].primitive]
+        loc = []
+        if pr.type == pt.PRIM_RECT:
+            x0, z0, x1, z1, y = list(pr.rect)
+            for (cx, cz) in ((x0, z0), (x0, z1), (x1, z0), (x1, z1), ((x0 + x1) / 2, z0), (x0, (z0 + z1) / 2), ((x0 + x1) / 2, (z0 + z1) / 2)):
+                c = (cx, y, cz)
+                loc.append({0: (c[0], c[2], c[1]), 1: c, 2: (c[1], c[0], c[2])}[pr.plane])
+        elif pr.type == pt.PRIM_BOX:
+            p0, p1 = list(pr.p0), list(pr.p1)
+            for a in (0, 1, 2):
+                for b in (0, 1, 2):
+                    for c in (0, 1, 2):
+                        loc.append(tuple(((p0[k], (p0[k] + p1[k]) / 2, p1[k])[s]) for k, s in enumerate((a, b, c))))
+        if loc:
+            L = np.array(loc, np.float64)
+            M = fwd[i].astype(np.float64).reshape(3, 4)
+            targets.append(L @ M[:, :3].T + M[:, 3])
+    targets = np.concatenate(targets) if targets else np.zeros((0, 3))
+    mn, mx = bbox[:, :3].min(0).astype(np.float64), bbox[:, 3:].max(0).astype(np.float64)
+    ext = np.maximum(mx - mn, 1.0)
+    o, d = [], []
+    # random -> random
+    src = mn - 0.25 * ext + rng.random((n_random, 3)) * 1.5 * ext
+    dst = mn + rng.random((n_random, 3)) * ext
+    o.append(src); d.append((dst - src) * rng.choice([1e-2, 1.0, 37.0], (n_random, 1)))
+    # several origins -> every target, exactly and a few float32 ulps around it
+    srcs = mn + rng.random((24, 3)) * ext
+    for s in srcs:
+        for k in (0, 1, -1, 3, -4):
+            tg = np.nextafter(targets.astype(F), (np.inf if k > 0 else -np.inf) * np.ones_like(targets, F)) if k else targets.astype(F)
+            for _ in range(max(abs(k) - 1, 0)):
+                tg = np.nextafter(tg, (np.inf if k > 0 else -np.inf) * np.ones_like(tg))
+            o.append(np.repeat(s[None], len(targets), 0)); d.append(tg.astype(np.float64) - s.astype(F).astype(np.float64))
+    # origins ON the surfaces (the targets themselves) towards other targets: shadow-ray-like, t of the own surface ~ 0
+    if len(targets) > 1:
+        idx = rng.integers(0, len(targets), (20000, 2))
+        o.append(targets[idx[:, 0]]); d.append(targets[idx[:, 1]] - targets[idx[:, 0]])
+    o = np.concatenate(o).astype(F)
+    d = np.concatenate(d).astype(F)
+    keep = _tame(o).all(1) & (d != 0).all(1) & _tame(d).all(1)
+    o, d = o[keep], d[keep]
+    n = (len(o) // 256) * 256   # whole workgroups of tame rays only
+    return o[:n], d[:n]
+
+
+@pytest.mark.parametrize("scene", ALL_SCENES)
+def test_fast_sweep_matches_oracle_and_general_sweep(oracle, scene, monkeypatch):
+    """Every ray here takes world_hit_fast on the device (all lanes tame).  It must equal the oracle's World::hit bit
+    for bit, and so must the general sweep on the same rays (PATHTRACE_HIP_NO_FASTDIV=1 switches the fast one off)."""
+    rng = np.random.default_rng(21)
+    sc = pt.Scene(scene_path(scene), 64, 64)
+    o, d = tame_rays(rng, sc)
+    assert len(o) > 30000
+    osc = oracle.Scene.from_json(scene_path(scene))
+    k0, k1, vd = 0x7654321, 0x0fedcba9, 24
+    hit, ot, inst = osc.world_hit_stream(o, d, k0, k1, vd)
+    results = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("PATHTRACE_HIP_NO_FASTDIV", env)
+        else:
+            monkeypatch.delenv("PATHTRACE_HIP_NO_FASTDIV", raising=False)
+        r = pt.Renderer(sc, max_paths_in_flight=4096)
+        t, ids = r.trace_rays(o, d, k0, k1, vd)
+        ginst = np.where(ids >= 0, ids >> 3, -1)
+        assert np.array_equal(ginst, inst), (env, int((ginst != inst).sum()), int(np.argmax(ginst != inst)))
+        ok = same_t(t, ot) | (hit == 0)
+        assert ok.all(), (env, int((~ok).sum()), int(np.argmin(ok)))
+        for nr in (2, 4):
+            nn = (len(o) // (256 * nr)) * 256 * nr
+            dn = d[:nn].reshape(-1, nr, 3)
+            on = o[:nn:nr]
+            tn, idn = r.trace_rays(on, dn, k0, k1, vd)
+            results.append((env, nr, tn.copy(), idn.copy()))
+            for k in range(nr):
+                h2, ot2, inst2 = osc.world_hit_stream(on, dn[:, k], k0, k1, vd + 16 * k)
+                g2 = np.where(idn[:, k] >= 0, idn[:, k] >> 3, -1)
+                assert np.array_equal(g2, inst2), (env, nr, k)
+                assert (same_t(tn[:, k], ot2) | (h2 == 0)).all(), (env, nr, k)
+        results.append((env, 1, t.copy(), ids.copy()))
+        r.close()
+    monkeypatch.delenv("PATHTRACE_HIP_NO_FASTDIV", raising=False)
+    # fast == general including the face of the hit (ids, not only instances)
+    by = {(e, nr): (t_, i_) for e, nr, t_, i_ in results}
+    for nr in (1, 2, 4):
+        tf, idf = by[(None, nr)]
+        tg, idg = by[("1", nr)]
+        assert np.array_equal(idf, idg), nr
+        assert (same_t(tf, tg) | (idf < 0)).all(), nr
+    assert (ids >= 0).sum() > 5000

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Static instruction-class statistics of the gfx950 kernels (CPU only: hipcc cross-compiles).
+
+    python tools/isa_stats.py [--kernel SUBSTR] [--blocks] [--flags "..."]
+
+Compiles pathtrace_amd/csrc/device/pt_kernels.hip to assembly with the product's flags and prints, per kernel:
+registers, spills, occupancy, and the instruction mix split by the issue classes measured on MI355X:
+  fp2   v_mul/add/sub/fma_f32 whose operands are VGPRs / constants only  (2 cycles per wave64 instruction)
+  fp2s  the same with an SGPR operand                                     (4 cycles)
+  v4    every other VALU instruction (compare, select, min/max, integer, convert, div scaffolding)  (4 cycles)
+  trans v_rcp/rsq/sqrt/exp/log/sin/cos_f32, f64 arithmetic                (8+ cycles)
+--blocks lists the basic blocks of the selected kernels with their mixes (the traversal sweep's per-op bodies).
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FP2 = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fma_f32", "v_mac_f32", "v_fmac_f32", "v_mad_f32",
+       "v_mul_legacy_f32", "v_fmaak_f32", "v_fmamk_f32"}
+TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
+
+
+def classify(op, args):
+    if op.startswith("v_"):
+        base = re.sub(r"_e32$|_e64$|_dpp$|_sdwa$", "", op)
+        if base.startswith(TRANS) or base.endswith("_f64") or "_f64_" in base:
+            return "trans"
+        if base in FP2:
+            # an SGPR source operand (s12, s[4:5], vcc, ...) puts the instruction in the 4-cycle class
+            srcs = args.split(",")[1:]
+            if any(re.match(r"\s*-?\|?(s\d+|s\[|vcc|ttmp|m0|exec)", s) for s in srcs):
+                return "fp2s"
+            return "fp2"
+        if base.startswith("v_pk_"):
+            return "pk"
+        return "v4"
+    if op.startswith("s_load") or op.startswith("s_buffer_load"):
+        return "smem"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    if op.startswith("ds_"):
+        return "lds"
+    return "other"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="")
+    ap.add_argument("--blocks", action="store_true")
+    ap.add_argument("--flags", default="")
+    ap.add_argument("--src", default=os.path.join(ROOT, "pathtrace_amd", "csrc", "device", "pt_kernels.hip"))
+    ap.add_argument("--keep", default="")
+    args = ap.parse_args()
+    from pathtrace_amd import build as ptb
+    flags = [f for f in ptb.FLAGS if f not in ("-shared", "-fPIC")] + args.flags.split()
+    out = args.keep or os.path.join(tempfile.mkdtemp(), "k.s")
+    cmd = [ptb.HIPCC] + flags + ["-S", "--cuda-device-only", args.src, "-o", out]
+    subprocess.run(cmd, check=True)
+    text = open(out).read()
+    # kernels: from "<sym>:" (a .globl function) to ".Lfunc_end"
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
+        sym, body = m.group(1), m.group(2)
+        name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().split("(")[0]
+        if args.kernel not in name:
+            continue
+        meta = {}
+        mm = re.search(r"\.amdhsa_kernel " + re.escape(sym) + r"\n(.*?)\.end_amdhsa_kernel", text, re.S)
+        if mm:
+            for k in ("next_free_vgpr", "next_free_sgpr", "group_segment_fixed_size", "private_segment_fixed_size"):
+                v = re.search(r"\.amdhsa_" + k + r" (\S+)", mm.group(1))
+                meta[k] = v.group(1) if v else "?"
+        tail = text[m.end(): m.end() + 3000]
+        info = {k: (re.search(r"; " + k + r": (\S+)", tail) or [None, "?"])[1] for k in
+                ("NumSgprs", "NumVgprs", "ScratchSize", "Occupancy", "LDSByteSize")}
+        spills = {k: (re.search(r"\." + k + r":\s+(\d+)", text[text.find(sym, text.find("amdhsa.kernels")):][:3000]) or [None, "?"])[1]
+                  for k in ("sgpr_spill_count", "vgpr_spill_count")}
+        blocks = []
+        cur = ["entry", {}]
+        tot = {}
+        for line in body.splitlines():
+            line = line.split(";")[0].rstrip()
+            if not line.strip():
+                continue
+            lab = re.match(r"^(\.LBB\w+):", line)
+            if lab:
+                blocks.append(cur)
+                cur = [lab.group(1), {}]
+                continue
+            s = line.strip()
+            if s.startswith("."):
+                continue
+            parts = s.split(None, 1)
+            op, a = parts[0], (parts[1] if len(parts) > 1 else "")
+            c = classify(op, a)
+            cur[1][c] = cur[1].get(c, 0) + 1
+            tot[c] = tot.get(c, 0) + 1
+            if op.startswith("v_div_") or op.startswith("v_rcp_"):
+                cur[1]["div*"] = cur[1].get("div*", 0) + 1
+                tot["div*"] = tot.get("div*", 0) + 1
+        blocks.append(cur)
+        keys = ("fp2", "fp2s", "v4", "pk", "trans", "salu", "smem", "vmem", "lds", "div*")
+        print(f"{name}\n   vgpr {info['NumVgprs']} sgpr {info['NumSgprs']} scratch {info['ScratchSize']} occupancy {info['Occupancy']} "
+              f"sgpr_spills {spills['sgpr_spill_count']} vgpr_spills {spills['vgpr_spill_count']} lds {info['LDSByteSize']}")
+        print("   static: " + "  ".join(f"{k} {tot.get(k, 0)}" for k in keys))
+        if args.blocks:
+            for lab, d in blocks:
+                n = sum(v for k, v in d.items() if k != "div*")
+                if n >= 12:
+                    print(f"      {lab:14s} {n:5d}: " + "  ".join(f"{k} {d.get(k, 0)}" for k in keys if d.get(k, 0)))
+
+
+if __name__ == "__main__":
+    main()

@@ -15,10 +15,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 timeout -k 10 500 python3 "$R/bench.py" > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench.err" || { echo "bench failed"; tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
 cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -- python3 "$R/bench.py" --no-cpu-baseline > "$OUT/${TAG}_prof.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/${TAG}_prof.log"; exit 1; }
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/${TAG}_pmc_fetch.log"; exit 1; }
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmc_write" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/${TAG}_pmc_write.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -- python3 "$R/bench.py" --no-cpu-baseline --no-configs > "$OUT/${TAG}_prof.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/${TAG}_prof.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/${TAG}_pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/${TAG}_pmc_fetch.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmc_write" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/${TAG}_pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/${TAG}_pmc_write.log"; exit 1; }
 # 4. instruction counters (own pass, serialised dispatches): the kernels are VALU / scalar-unit bound, not HBM bound
-timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${TAG}_pmc_insts" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_pmc_insts.log" 2>&1 || { echo "pmc insts failed"; tail -5 "$OUT/${TAG}_pmc_insts.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${TAG}_pmc_insts" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/${TAG}_pmc_insts.log" 2>&1 || { echo "pmc insts failed"; tail -5 "$OUT/${TAG}_pmc_insts.log"; exit 1; }
 cd "$R"
 python3 tools/summarize_profiles.py "$TAG" "$OUT"

@@ -49,9 +49,10 @@ def pmc_per_launch(d, counter):
 
 def insts_per_kernel(d):
     """Per kernel, over all its dispatches of the counter pass (dispatches are serialised there): instruction counts per
-    wave and the share of the one-wide VALU issue rate the kernel sustained.  A wave64 VALU instruction occupies its SIMD
-    for 4 cycles, so a chip of 256 CUs x 4 SIMDs issues at most 1024 * f / 4 of them per second; f is taken from
-    GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch time, i.e. the clock the dispatch actually ran at."""
+    wave and the share of the vector issue roof the kernel sustained.  A wave64 FP32 mul/add/fma occupies its SIMD for 2
+    cycles (MI355X_MICROARCH.md; every other class 4 or more), so a chip of 256 CUs x 4 SIMDs issues at most
+    1024 * f / 2 vector instructions per second; f is taken from GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch
+    time, i.e. the clock the dispatch actually ran at."""
     f = find(d, "counter_collection.csv")
     if not f:
         return {}
@@ -69,7 +70,7 @@ def insts_per_kernel(d):
         t = sum(dur[k].values())
         waves = max(c.get("SQ_WAVES", 0.0), 1.0)
         clock = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t if t > 0 else 0.0
-        peak = 1024.0 * clock / 4.0
+        peak = 1024.0 * clock / 2.0
         out[k] = {"dispatches": len(dur[k]), "seconds": round(t, 6), "waves": int(waves),
                   "valu_per_wave": round(c.get("SQ_INSTS_VALU", 0) / waves, 1),
                   "salu_per_wave": round(c.get("SQ_INSTS_SALU", 0) / waves, 1),
@@ -103,12 +104,12 @@ def main():
             wk, _ = write[k]
             res[k] = {"launches_sampled": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-    json.dump(res, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1)
     ins = insts_per_kernel(os.path.join(d, tag + "_pmc_insts"))
     if ins:
         ins["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS "
                        "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/profile_gpu.sh " + tag + "), bench.py --steps 4 "
-                       "--warmup 1; valu_issue_fraction = wave64 VALU instructions per second / (1024 SIMDs * clock / 4)")
+                       "--warmup 1; valu_issue_fraction = wave64 VALU instructions per second / (1024 SIMDs * clock / 2), the FP32 mul/add/fma rate")
         json.dump(ins, open(os.path.join(out, tag + "_instruction_mix.json"), "w"), indent=1)
         print(json.dumps({k: v for k, v in ins.items() if k != "note"}))
     print(json.dumps({k: v for k, v in res.items() if k != "note"}))
