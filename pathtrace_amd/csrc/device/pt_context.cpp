@@ -219,6 +219,65 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
     return 0;
 }
 
+// ---- per-face hit record table (pt_device.h PT_FACE_F4).  Plain float arithmetic in the association of the device code
+// (pt_kernels.hip xf_normal / vunit / onb_from_w); this file is compiled with -ffp-contract=off like the kernels.
+namespace {
+struct hv3 { float x, y, z; };
+inline hv3 h_xf_normal(const float *inv, hv3 n)
+{   // normalize((L^-1)^T n), Eigen's norm association x2 + (y2 + z2)   (transform3.h:60-63)
+    const float x = (inv[0] * n.x + inv[4] * n.y) + inv[8] * n.z;
+    const float y = (inv[1] * n.x + inv[5] * n.y) + inv[9] * n.z;
+    const float z = (inv[2] * n.x + inv[6] * n.y) + inv[10] * n.z;
+    const float nrm = sqrtf(x * x + (y * y + z * z));
+    return hv3{x / nrm, y / nrm, z / nrm};
+}
+inline hv3 h_vunit(hv3 v)
+{   // vec3.h unit_vector: v / sqrt(x*x + y*y + z*z)
+    const float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return hv3{v.x / l, v.y / l, v.z / l};
+}
+inline hv3 h_cross(hv3 a, hv3 b) { return hv3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline hv3 h_shuffle(hv3 v, int plane)
+{   // primitive.h:104-121
+    if (plane == 0) return hv3{v.x, v.z, v.y};
+    if (plane == 2) return hv3{v.y, v.x, v.z};
+    return v;
+}
+void face_side(const float *inv, hv3 nl, float4 *out3)
+{
+    const hv3 n = h_xf_normal(inv, nl);
+    const hv3 w = h_vunit(n);                                             // helpers.h:127-136
+    const hv3 a = (fabsf(w.x) > 0.9) ? hv3{0.0f, 1.0f, 0.0f} : hv3{1.0f, 0.0f, 0.0f};
+    const hv3 v = h_vunit(h_cross(w, a));
+    const hv3 u = h_cross(w, v);
+    out3[0] = make_float4(n.x, n.y, n.z, w.x);
+    out3[1] = make_float4(w.y, w.z, u.x, u.y);
+    out3[2] = make_float4(u.z, v.x, v.y, v.z);
+}
+}  // namespace
+static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim> &prims, std::vector<float4> &faces)
+{
+    faces.assign(insts.size() * 8 * PT_FACE_F4, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t i = 0; i < insts.size(); i++) {
+        const DPrim &pr = prims[insts[i].prim];
+        for (int f = 0; f < 8; f++) {
+            float4 *out = &faces[(i * 8 + f) * PT_FACE_F4];
+            hv3 nl{1.0f, 0.0f, 0.0f};                                      // constant_medium: volume.h:85
+            if (pr.type <= 1) {                                             // rect (face 0) / box side: primitive.h:212
+                const DRect &q = pr.r[(pr.type == 0) ? 0 : std::min(f, 5)];
+                nl = h_shuffle(hv3{0.0f, q.ny, 0.0f}, q.plane);
+            }
+            const int32_t head = pr.hit_mat[f] | (pr.type << 24);
+            float hb;
+            memcpy(&hb, &head, 4);
+            out[0] = make_float4(hb, nl.x, nl.y, nl.z);
+            if (pr.type == 2) continue;                                     // sphere: the normal depends on the hit point
+            face_side(insts[i].inv, nl, out + 1);
+            face_side(insts[i].inv, hv3{-nl.x, -nl.y, -nl.z}, out + 4);     // vec3 operator-: (-x, -y, -z)
+        }
+    }
+}
+
 static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
 {
     if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_materials < 1 || sc->n_nodes < 1) {
@@ -233,6 +292,9 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         d.type = m.type; d.r = m.color[0]; d.g = m.color[1]; d.b = m.color[2];
         d.alpha = m.alpha; d.power = m.power; d.two_sided = m.two_sided;
         d.tex = -1;
+        // lambertian::scatter / metal::scatter: attenuation = albedo->value(..) / M_PI with M_PI narrowed to float by
+        // vec3::operator/(float) (material.h:46, 94; vec3.h): the same three float divisions the kernel performed per hit
+        d.att[0] = d.r / 3.14159274f; d.att[1] = d.g / 3.14159274f; d.att[2] = d.b / 3.14159274f;
         if (m.texture >= 0) {
             if (m.texture >= sc->n_textures) { set_err("pt_create: material %d: bad texture index %d", i, m.texture); return -1; }
             // metal's albedo is a plain colour and a dielectric has none (material.h:79, 113-117)
@@ -424,6 +486,9 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     if (texs.empty()) texs.push_back(DTex{});
     if (texels.empty()) texels.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     DScene &S = c->S;
+    std::vector<float4> faces;
+    build_faces(insts, prims, faces);
+    if (dev_upload(c, &S.faces, faces)) return -1;
     if (dev_upload(c, &S.emit, emit)) return -1;
     if (dev_upload(c, &S.tex, texs) || dev_upload(c, &S.texels, texels) || dev_upload(c, &S.ranvec, ranvec) || dev_upload(c, &S.perm, perm))
         return -1;

@@ -32,13 +32,25 @@ struct DInst {           // 112 bytes
     int32_t ident;       // 1 if the linear parts of inv and fwd are exactly the identity (pure translation)
     int32_t pad[1];
 };
-struct DMat {            // 32 bytes
+struct DMat {            // 48 bytes
     int32_t type;
     float r, g, b;
     float alpha, power;
     int32_t two_sided;
     int32_t tex;         // albedo / emit texture (DScene::tex index) when it is not a constant one, else -1
+    float att[3];        // lambertian / metal with a constant albedo: albedo / float(M_PI), the attenuation scatter() returns
+                         // (material.h:46, 94), divided once on the host with the same IEEE float division
+    int32_t pad;
 };
+// Per hit id (instance * 8 + face): everything of the hit record that does not depend on where the face was hit, computed
+// once on the host with the float operations the kernels would perform per hit (pt_context.cpp build_faces; both sides
+// are compiled without FMA contraction, IEEE division and square root): the face's material, its local normal, and for
+// both outcomes of rect::hit's facing test (primitive.h:214-222) the world normal  transform.apply_normal(n)
+// (transform3.h:60-63), that normal normalised once more (every consumer -- cos_i integrator.h:201, cosine_pdf pdf.h:18-29,
+// cos_l integrator.h:236 -- calls unit_vector on it) and the onb built from it (helpers.h:127-136).
+// Eight float4 per id:  [0] = bits(mat | ptype << 24), local normal xyz;  [1..3] normal kept:  n.xyz nu.x | nu.yz u.xy |
+// u.z v.xyz;  [4..6] normal flipped, same layout;  [7] unused.  A sphere's normal depends on the hit point: ptype says so.
+#define PT_FACE_F4 8
 // texture.h / image.h.  Read with per-lane indices (which child a checker picks depends on the hit point).
 struct DTex {            // 48 bytes
     int32_t type;        // PT_TEX_*
@@ -89,6 +101,7 @@ struct DScene {
     const DMat *mats;
     const DOp *ops;
     const int32_t *lights;
+    const float4 *faces;         // [n_insts*8][PT_FACE_F4] by hit id, see above
     const float4 *emit;          // [n_insts*8] by hit id: emitted radiance of that face's material (xyz); w = 0: that is
                                  // all; w bit 0: one-sided diffuse_light (facing test of material.h:214-216), bit 1:
                                  // textured emit (value/alpha at the hit point) -- both need the hit record

@@ -1145,6 +1145,65 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
 // material scatter + emission/MIS, light sampling -> shadow records, BSDF sampling + russian roulette ->
 // continuation ray; survivors are compacted into the next path queue, shadow records into the shadow queue.
 // ------------------------------------------------------------------------------------------------
+// hit_record of the winning primitive for k_shade: rec.p, rec.normal, rec.mat_ptr (primitive.h:186-225, 298-312;
+// volume.h:77-88) plus unit_vector(rec.normal) and the onb of it.  Everything that does not depend on where the face was
+// hit comes from the per-face table (pt_device.h PT_FACE_F4), computed on the host with the same float operations; what
+// is left per hit is the local hit point, rec.p = transform * p_local and the facing test.
+struct ShadeHit { v3 p, n, nu, ou, ov, pl; int mat; };
+DEVI ShadeHit shade_hit(const DScene &S, v3 A, v3 B, float t, int id)
+{
+    const DInst &in = S.insts[id >> 3];
+    const float4 *fc = S.faces + (size_t)id * PT_FACE_F4;
+    const float4 h0 = fc[0];
+    const int head = __float_as_int(h0.x);
+    const int ptype = head >> 24;
+    const v3 Al = xf_point(in.inv, A);
+    const v3 Bl = xf_linear(in.inv, B);
+    ShadeHit h;
+    h.pl = vadd(Al, vscale(t, Bl));   // r.point_at_parameter(t) in local space
+    h.p = xf_point(in.fwd, h.pl);
+    h.mat = head & 0xffffff;
+    if (ptype != 2) {
+        // rect / box side: "if (dot(r.direction(), normal) > 0) normal = -normal" (primitive.h:214-222); volume: no test
+        const bool flip = (ptype <= 1) && (vdot(Bl, V(h0.y, h0.z, h0.w)) > 0);
+        const float4 *sd = fc + (flip ? 4 : 1);
+        const float4 a = sd[0], b = sd[1], c = sd[2];
+        h.n = V(a.x, a.y, a.z);
+        h.nu = V(a.w, b.x, b.y);
+        h.ou = V(b.z, b.w, c.x);
+        h.ov = V(c.y, c.z, c.w);
+    } else {   // sphere::hit primitive.h:76-78: normal = (p - center) / radius, per hit
+        const DPrim &pr = S.prims[in.prim];
+        const v3 nl = vdivf(vsub(h.pl, V(pr.cx, pr.cy, pr.cz)), pr.radius);
+        h.n = xf_normal(in.inv, nl);
+        const Onb o = onb_from_w(h.n);
+        h.nu = o.w; h.ou = o.u; h.ov = o.v;
+    }
+    return h;
+}
+// cosine_pdf::value (pdf.h:18-29) given cosine = dot(unit_vector(direction), unit_vector(normal))
+DEVI float cosine_pdf_of(float cosine)
+{
+    if (cosine > 0) {
+        // The reference computes (float)((double)cosine / M_PI).  q = cosine * RN(1/pi) is within 3 ulp(double) of
+        // d = RN(cosine / pi), so (float)q == (float)d unless a float rounding boundary (low 29 mantissa bits =
+        // 0x10000000) lies within a few double ulps of q; only then (about 1 call in 10^7), or when the result could be
+        // a float denormal, pay for the IEEE double division.
+        const double q = (double)cosine * 0.31830988618379067154;
+        const unsigned lo = (unsigned)__double2loint(q) & 0x1fffffffu;
+        if (lo - 0x0ffffff0u <= 0x20u || !(cosine > 1e-30f)) return (float)((double)cosine / PT_PI_D);
+        return (float)q;
+    }
+    return 0.0f;
+}
+// material::value(r_in, rec, direction) (material.h:66-69, 105-108; pdf.h:41-44) given that cosine
+DEVI float material_value_of(int type, float cosine)
+{
+    if (type == 0 || type == 1) return cosine_pdf_of(cosine);
+    if (type == 4) return (float)(1 / (4 * PT_PI_D));
+    return 0.0f;   // void_pdf
+}
+
 // LM: how the light of an NEE sample is found -- 1: the scene has one light (scalar records), 2: two lights (both records
 // scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
 // of the others.
@@ -1155,24 +1214,22 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
-    __shared__ int sh4[PT_BLOCK / 64];
+    __shared__ int sh_cnt[2][PT_BLOCK / 64];
     __shared__ int sh_base[2];
-    __shared__ unsigned int sh_ctr[C_N];
     const int cps = b.seg_cap / PT_BLOCK;
     const int total_chunks = b.n_seg * cps;
     const DQueue q = st.q[qi];
     const DQueue qo = st.q[qi ^ 1];
     const DShadowQueue sq = st.sq;
-    if (threadIdx.x < C_N) sh_ctr[threadIdx.x] = 0;
-    __syncthreads();
     const long long P = b.P;
     const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
     const uint32_t D = NV + L * (3u + NV) + 4u;
     const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
     const uint32_t gb = base + NV + L * (3u + NV);
     const bool last_bounce = (bounce + 1 >= S.max_bounces);
-    const float pick_pdf = (float)S.n_lights;   // integrator.h:224
-    (void)pick_pdf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // path counters: one popcount of a ballot per event and chunk, kept in scalar registers, flushed once per wave
+    unsigned n_miss = 0, n_hit = 0, n_rr = 0, n_emit = 0, n_pdf = 0, n_limit = 0;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
         const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;   // chunk-major, see k_extend
         const int n = q.count[seg];
@@ -1184,10 +1241,10 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
         const int i = i0 + threadIdx.x;
         const bool valid = i < n;
         bool cont = false, shadow = false, pending = false;
-        v3 A = V(0, 0, 0), B = V(0, 0, 0);
+        bool ev_miss = false, ev_rr = false, ev_emit = false, ev_pdf = false, ev_limit = false;
         v3 beta = V(0, 0, 0), att = V(0, 0, 0);      // beta BEFORE this bounce's update; attenuation AFTER scatter()
         v3 nA = V(0, 0, 0), nB = V(0, 0, 0), nbeta = V(0, 0, 0);
-        v3 hp = V(0, 0, 0), hn = V(0, 0, 0);
+        v3 hp = V(0, 0, 0), hnu = V(0, 0, 0);
         float new_pdf = 0.0f;
         uint32_t k0 = 0, k1 = 0;
         int slot = 0, mat_type = 0;
@@ -1195,8 +1252,8 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             const long long pos = seg_base + i;
             const float4 r0 = q.r0[pos], r1 = q.r1[pos], s0 = q.s0[pos], s1 = q.s1[pos];
             const float2 h = st.hit[pos];
-            A = V(r0.x, r0.y, r0.z);
-            B = V(r1.x, r1.y, r1.z);
+            const v3 A = V(r0.x, r0.y, r0.z);
+            const v3 B = V(r1.x, r1.y, r1.z);
             slot = __float_as_int(r0.w);
             const float last_bsdf_pdf = r1.w;
             beta = V(s0.x, s0.y, s0.z);
@@ -1220,28 +1277,34 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                 const float4 rad = st.radiance[slot];
                 const v3 add = vmul(beta, bg);
                 st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
-                atomicAdd(&sh_ctr[C_MISS], 1u);
+                ev_miss = true;
             } else {
-                atomicAdd(&sh_ctr[C_EXT_HITS], 1u);
-                const HitInfo hi = finalize_hit(S, A, B, h.x, id, true);
+                const ShadeHit hi = shade_hit(S, A, B, h.x, id);
                 const DMat m = S.mats[hi.mat];
                 mat_type = m.type;
                 hp = hi.p;
-                hn = hi.n;
+                hnu = hi.nu;
+                HitInfo hti;   // the texture / emission helpers' view of the record
+                hti.p = hi.p; hti.n = hi.n; hti.mat = hi.mat; hti.pl = hi.pl;
                 // scatter(): material.h:39-53 lambertian, :90-98 metal, :187-191 diffuse_light (attenuation keeps
-                // its previous value), :252-261 isotropic
+                // its previous value), :252-261 isotropic.  A constant albedo / pi comes from the table.
                 bool did_scatter = true;
                 v3 albedo = V(m.r, m.g, m.b);
-                if (TEX && m.tex >= 0 && m.type != 3) { float ta; material_texture(S, m, id, hi, albedo, ta); }   // albedo->value(rec.u, rec.v, rec.p)
+                v3 att_l = V(m.att[0], m.att[1], m.att[2]);
+                if (TEX && m.tex >= 0 && m.type != 3) {   // albedo->value(rec.u, rec.v, rec.p)
+                    float ta;
+                    material_texture(S, m, id, hti, albedo, ta);
+                    att_l = vdivf(albedo, PT_PI_F);
+                }
                 if (m.type == 0) {
-                    if (vdot(B, hi.n) < 0) att = vdivf(albedo, PT_PI_F);
+                    if (vdot(B, hi.n) < 0) att = att_l;
                     else att = V(0.0f, 0.0f, 0.0f);
-                } else if (m.type == 1) att = vdivf(V(m.r, m.g, m.b), PT_PI_F);
+                } else if (m.type == 1) att = V(m.att[0], m.att[1], m.att[2]);   // metal: its own colour (material.h:94)
                 else if (m.type == 2) att = V(1.0f, 1.0f, 1.0f);   // dielectric::scatter material.h:118-124
                 else if (m.type == 3) did_scatter = false;
                 else if (m.type == 4) att = albedo;
-                const float cos_i = fabsf(vdot(vunit(B), vunit(hi.n)));
-                const v3 hit_emission = material_emitted<TEX>(S, m, id, hi, B);
+                const float cos_i = fabsf(vdot(vunit(B), hi.nu));
+                const v3 hit_emission = material_emitted<TEX>(S, m, id, hti, B);
                 if ((double)vsqlen(hit_emission) > 0.000001) {   // integrator.h:205-218
                     v3 add;
                     if (last_bsdf_pdf <= 0) add = vmul(beta, hit_emission);
@@ -1256,23 +1319,36 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                 shadow = true;
                 if (did_scatter) {   // integrator.h:271-316
                     nA = vadd(hi.p, vscale(S.normal_offset, hi.n));
-                    nB = material_generate(m.type, hi.n, k0, k1, gb);
-                    const float scatter_pdf_s = material_value(m.type, hi.n, nB);
+                    float scatter_pdf_s;
+                    if (m.type == 0 || m.type == 1) {   // cosine_pdf::generate pdf.h:30-33, random.h:36-44 over the table's onb
+                        const float r1 = rndf(k0, k1, gb + 0);
+                        const float r2 = rndf(k0, k1, gb + 1);
+                        const float z = sqrtf(1 - r2);
+                        float sn, cs;
+                        ptm_sincos_2pi(r1, sn, cs);
+                        const float x = cs * sqrtf(r2);
+                        const float y = sn * sqrtf(r2);
+                        nB = vadd(vadd(vscale(x, hi.ou), vscale(y, hi.ov)), vscale(z, hi.nu));
+                        scatter_pdf_s = cosine_pdf_of(vdot(vunit(nB), hi.nu));
+                    } else {
+                        nB = material_generate(m.type, hi.n, k0, k1, gb);
+                        scatter_pdf_s = material_value_of(m.type, 0.0f);
+                    }
                     const float pin = (beta.y < beta.z) ? beta.z : beta.y;   // std::max(a,b) = (a<b)?b:a
                     const float p = (beta.x < pin) ? pin : beta.x;
                     bool alive = true;
                     nbeta = beta;
                     if (S.russian_roulette && p <= 1 && 0.001 < (double)p) {
-                        if (rnd(k0, k1, gb + 3) > (double)p) { alive = false; atomicAdd(&sh_ctr[C_RR], 1u); }
+                        if (rnd(k0, k1, gb + 3) > (double)p) { alive = false; ev_rr = true; }
                         else { const float ip = 1 / p; nbeta = V(beta.x * ip, beta.y * ip, beta.z * ip); }
                     }
                     if (alive) {
                         if (S.only_direct) alive = false;
-                        else if ((double)scatter_pdf_s < 0.0000001) { alive = false; atomicAdd(&sh_ctr[C_PDF], 1u); }
+                        else if ((double)scatter_pdf_s < 0.0000001) { alive = false; ev_pdf = true; }
                         else {
                             nbeta = vmul(nbeta, vdivf(vscale(fabsf(cos_i), att), scatter_pdf_s));
                             new_pdf = scatter_pdf_s;
-                            if (last_bounce) { alive = false; atomicAdd(&sh_ctr[C_LIMIT], 1u); }
+                            if (last_bounce) { alive = false; ev_limit = true; }
                         }
                     }
                     cont = alive;
@@ -1282,20 +1358,30 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                     const v3 add = vmul(beta, hit_emission);
                     st.pending[slot] = make_float4(add.x, add.y, add.z, 0.0f);
                     pending = true;
-                    atomicAdd(&sh_ctr[C_EMIT], 1u);
+                    ev_emit = true;
                 }
             }
         }
-        // ---- compaction: continuation rays -> next path queue, shadow records -> shadow queue ----
-        int tot_c, tot_s;
-        const int off_c = block_compact(cont, tot_c, sh4);
-        const int off_s = block_compact(shadow, tot_s, sh4);
-        // one atomicAdd per workgroup and queue reserves this chunk's range in the output segment
+        // ---- compaction: continuation rays -> next path queue, shadow records -> shadow queue.  One ballot per queue,
+        // one LDS exchange and one atomicAdd per workgroup and queue reserve this chunk's ranges in the output segment.
+        const unsigned long long mc = __ballot(cont), ms = __ballot(shadow);
+        n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(ms); n_rr += __popcll(__ballot(ev_rr));
+        n_emit += __popcll(__ballot(ev_emit)); n_pdf += __popcll(__ballot(ev_pdf)); n_limit += __popcll(__ballot(ev_limit));
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) { sh_cnt[0][wave] = __popcll(mc); sh_cnt[1][wave] = __popcll(ms); }
+        __syncthreads();
+        int off_c = __popcll(mc & below), off_s = __popcll(ms & below), tot_c = 0, tot_s = 0;
+#pragma unroll
+        for (int w = 0; w < PT_BLOCK / 64; w++) {
+            const int cc = sh_cnt[0][w], cs = sh_cnt[1][w];
+            if (w < wave) { off_c += cc; off_s += cs; }
+            tot_c += cc; tot_s += cs;
+        }
         if (threadIdx.x == 0) {
             sh_base[0] = tot_c ? atomicAdd(&qo.count[seg_o], tot_c) : 0;
             sh_base[1] = tot_s ? atomicAdd(&sq.count[seg_o], tot_s) : 0;
         }
-        __syncthreads();
+        __syncthreads();   // also orders this chunk's reads of sh_cnt before the next chunk's writes
         if (cont) {
             const long long o = seg_base_o + sh_base[0] + off_c;
             qo.r0[o] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
@@ -1311,6 +1397,19 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             if (NV) sq.key[o] = make_uint2(k0, k1);
             const bool att_ok = (double)vlen(att) > 0.0001;   // integrator.h:248
             const v3 ab = vmul(att, beta);
+            // the tail every sample shares: MIS weight, attenuation * beta * weight_l / light_pdf_l * dropoff
+            // (* light_emission / pick_pdf in connect), the record
+            auto emit_sample = [&](const uint32_t k, v3 ldir, float cos_l, float light_pdf_l) {
+                const float scatter_pdf_l = material_value_of(mat_type, cos_l);   // cosine_pdf's cosine IS cos_l (pdf.h:20)
+                const float weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
+                const float dropoff = cos_l > 0.0f ? cos_l : 0.0f;
+                v3 c = vscale(weight_l, ab);
+                c = vdivf(c, light_pdf_l);
+                c = vscale(dropoff, c);
+                if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
+                sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
+                sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+            };
             // one light (the common case): its index is wave-uniform, so its instance/primitive records are scalar
             // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
             // tr: the light's transform is a pure translation and every hit point of this wave is finite (same exactness
@@ -1319,23 +1418,47 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
                 const v3 ol = tr ? V(lin.inv[3] + hp.x, lin.inv[7] + hp.y, lin.inv[11] + hp.z) : xf_point(lin.inv, hp);
                 const v3 dl = prim_random(lpr, ol, k0, k1, kb + 1);                       // instance::random primitive.h:338-342
                 const v3 ldir = tr ? dl : xf_linear(lin.fwd, dl);
-                const float cos_l = vdot(vunit(ldir), vunit(hn));
+                const float cos_l = vdot(vunit(ldir), hnu);
                 const float light_pdf_l = prim_pdf_value(lpr, ol, tr ? ldir : xf_linear(lin.inv, ldir));   // primitive.h:319-337
-                const float scatter_pdf_l = material_value(mat_type, hn, ldir);
-                const float weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
-                const float dropoff = cos_l > 0.0f ? cos_l : 0.0f;
-                // attenuation * beta * weight_l / light_pdf_l * dropoff  (* light_emission / pick_pdf in connect)
-                v3 c = vscale(weight_l, ab);
-                c = vdivf(c, light_pdf_l);
-                c = vscale(dropoff, c);
-                if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
-                sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
-                sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+                emit_sample(k, ldir, cos_l, light_pdf_l);
             };
             if (LM == 1) {
                 const DInst &lin = S.insts[S.lights[0]];
+                const DPrim &lpr = S.prims[lin.prim];
                 const bool tr = lin.ident && wave_finite;
-                for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, S.prims[lin.prim], tr);
+                if (tr && lpr.type == 0) {
+                    // A rect light under a pure translation, sampled from a finite point: the pdf's ray (ol, ldir) is the one
+                    // rect::random just built, so rect::pdf_value (primitive.h:151-166) simplifies WITHOUT changing a bit:
+                    //  * its t = (y - o.y) / d.y divides a float by itself -- d.y = y - o.y is the same subtraction -- which
+                    //    is exactly 1 for a finite non-zero value and NaN otherwise (0 / 0);
+                    //  * dot(v, normal) has two exact-zero terms: |dot| = |v.y| for the finite v here.
+                    const DRect &lq = lpr.r[0];
+                    const v3 ol = V(lin.inv[3] + hp.x, lin.inv[7] + hp.y, lin.inv[11] + hp.z);
+                    const v3 os = shuffle(ol, lq.plane);
+                    const float area = (lq.x1 - lq.x0) * (lq.z1 - lq.z0);
+                    for (uint32_t k = 0; k < L; k++) {
+                        const uint32_t kb = base + NV + k * (3u + NV);
+                        const double rz = rnd(k0, k1, kb + 1);   // rect::random primitive.h:168-175 (first draw -> z, second -> x)
+                        const double rx = rnd(k0, k1, kb + 2);
+                        const float pz = (float)((double)lq.z0 + rz * (double)(lq.z1 - lq.z0));
+                        const float px = (float)((double)lq.x0 + rx * (double)(lq.x1 - lq.x0));
+                        const v3 ldir = vsub(shuffle(V(px, lq.y, pz), lq.plane), ol);
+                        const float vl = vlen(ldir);
+                        const float cos_l = vdot(vdivf(ldir, vl), hnu);
+                        const v3 ds = shuffle(ldir, lq.plane);
+                        const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
+                        const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
+                        float light_pdf_l = 0.0f;
+                        if (!(xh < lq.x0 || xh > lq.x1 || zh < lq.z0 || zh > lq.z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
+                            const float d2 = (tq * vl) * (tq * vl);
+                            const float cosine = fabsf(ds.y) / vl;
+                            light_pdf_l = d2 / (cosine * area);
+                        }
+                        emit_sample(k, ldir, cos_l, light_pdf_l);
+                    }
+                } else {
+                    for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, lpr, tr);
+                }
             } else if (LM == 2) {
                 // two lights (BASELINE config 3): both records come in by scalar loads and every lane selects the fields of the
                 // one it drew -- a few dozen v_cndmask instead of per-lane table gathers
@@ -1367,7 +1490,15 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
             }
         }
     }
-    flush_counters(sh_ctr, st.counters);
+    if (lane == 0) {
+        DCounters *cb = counter_bank(st.counters);
+        if (n_hit) atomicAdd(&cb->ext_hits, (unsigned long long)n_hit);
+        if (n_miss) atomicAdd(&cb->term_miss, (unsigned long long)n_miss);
+        if (n_rr) atomicAdd(&cb->term_rr, (unsigned long long)n_rr);
+        if (n_emit) atomicAdd(&cb->term_emitter, (unsigned long long)n_emit);
+        if (n_pdf) atomicAdd(&cb->term_pdf, (unsigned long long)n_pdf);
+        if (n_limit) atomicAdd(&cb->term_bounce_limit, (unsigned long long)n_limit);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
