@@ -255,7 +255,7 @@ void face_side(const float *inv, hv3 nl, float4 *out3)
     out3[2] = make_float4(u.z, v.x, v.y, v.z);
 }
 }  // namespace
-static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim> &prims, std::vector<float4> &faces)
+static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim> &prims, const std::vector<DMat> &mats, std::vector<float4> &faces)
 {
     faces.assign(insts.size() * 8 * PT_FACE_F4, make_float4(0.f, 0.f, 0.f, 0.f));
     for (size_t i = 0; i < insts.size(); i++) {
@@ -267,7 +267,11 @@ static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim
                 const DRect &q = pr.r[(pr.type == 0) ? 0 : std::min(f, 5)];
                 nl = h_shuffle(hv3{0.0f, q.ny, 0.0f}, q.plane);
             }
-            const int32_t head = pr.hit_mat[f] | (pr.type << 24);
+            // shading class of a hit on this face (k_shade's sort key): 0 untextured lambertian / metal on a rect or box,
+            // 2 emitter, 1 everything else
+            const DMat &fm = mats[pr.hit_mat[f]];
+            const int cls = (fm.type == PT_MAT_DIFFUSE_LIGHT) ? 2 : (((fm.type == PT_MAT_LAMBERTIAN || fm.type == PT_MAT_METAL) && fm.tex < 0 && pr.type <= 1) ? 0 : 1);
+            const int32_t head = pr.hit_mat[f] | (pr.type << 24) | (cls << 28);
             float hb;
             memcpy(&hb, &head, 4);
             out[0] = make_float4(hb, nl.x, nl.y, nl.z);
@@ -487,7 +491,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     if (texels.empty()) texels.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     DScene &S = c->S;
     std::vector<float4> faces;
-    build_faces(insts, prims, faces);
+    if (mats.size() >= (1u << 20)) { set_err("pt_create: too many materials"); return -1; }
+    build_faces(insts, prims, mats, faces);
     if (dev_upload(c, &S.faces, faces)) return -1;
     if (dev_upload(c, &S.emit, emit)) return -1;
     if (dev_upload(c, &S.tex, texs) || dev_upload(c, &S.texels, texels) || dev_upload(c, &S.ranvec, ranvec) || dev_upload(c, &S.perm, perm))
@@ -753,6 +758,7 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
         b.n_seg_out = b.n_seg; b.seg_cap_out = b.seg_cap;
         b.P = c->P;
+        b.sort_shade = getenv("PATHTRACE_HIP_NO_SORT") ? 0 : 1;
         if (run_batch(c, b)) return -1;
         s += ns;
     }

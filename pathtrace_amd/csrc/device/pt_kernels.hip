@@ -607,7 +607,8 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 const float az = dz0 * inv[r].z, cz = dz1 * inv[r].z;
                 const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
                 const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
-                skipf[r] = fmaxf(skipf[r], (tmax <= tmin) ? endf : 0.0f);
+                // max of two non-negative floats, taken on their bit patterns (same order, no NaN-quieting instruction)
+                skipf[r] = __int_as_float(max(__float_as_int(skipf[r]), (tmax <= tmin) ? __float_as_int(endf) : 0));
                 in_max = fminf(in_max, skipf[r] - pcf);
             }
             if (!__any(in_max <= 0.0f)) pc = op_a - 1;   // no ray of the wave is inside this subtree: jump to its end
@@ -1156,13 +1157,13 @@ DEVI ShadeHit shade_hit(const DScene &S, v3 A, v3 B, float t, int id)
     const float4 *fc = S.faces + (size_t)id * PT_FACE_F4;
     const float4 h0 = fc[0];
     const int head = __float_as_int(h0.x);
-    const int ptype = head >> 24;
+    const int ptype = (head >> 24) & 15;
     const v3 Al = xf_point(in.inv, A);
     const v3 Bl = xf_linear(in.inv, B);
     ShadeHit h;
     h.pl = vadd(Al, vscale(t, Bl));   // r.point_at_parameter(t) in local space
     h.p = xf_point(in.fwd, h.pl);
-    h.mat = head & 0xffffff;
+    h.mat = head & 0xfffff;
     if (ptype != 2) {
         // rect / box side: "if (dot(r.direction(), normal) > 0) normal = -normal" (primitive.h:214-222); volume: no test
         const bool flip = (ptype <= 1) && (vdot(Bl, V(h0.y, h0.z, h0.w)) > 0);
@@ -1216,6 +1217,8 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     __shared__ int sh_cnt[2][PT_BLOCK / 64];
     __shared__ int sh_base[2];
+    __shared__ int sh_key[3][PT_BLOCK / 64];
+    __shared__ unsigned char sh_perm[PT_BLOCK];
     const int cps = b.seg_cap / PT_BLOCK;
     const int total_chunks = b.n_seg * cps;
     const DQueue q = st.q[qi];
@@ -1238,7 +1241,40 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
         const long long seg_base = (long long)seg * b.seg_cap;
         const int seg_o = b.n_seg_out == b.n_seg ? seg : (seg >> 1);
         const long long seg_base_o = (long long)seg_o * b.seg_cap_out;
-        const int i = i0 + threadIdx.x;
+        // ---- material-sorted shading order inside the chunk (north_star: per-bounce material-sorted shading queues).
+        // The 256 paths of a chunk are partitioned by what their hit needs -- 0: untextured lambertian / metal on a rect or
+        // box (the long path), 1: every other scattering hit (textures, dielectric, fog, sphere normals), 2: emitters,
+        // 3: misses and the unused tail -- with one counting sort in LDS (four ballots per wave, one exchange), so that
+        // whole waves run one kind of work instead of every wave running all of them at partial occupancy.  Per-path
+        // arithmetic does not depend on the lane that performs it, so the image does not change.
+        int src = threadIdx.x;
+        if (b.sort_shade) {
+            int key = 3;
+            if (i0 + (int)threadIdx.x < n) {
+                const int hid = __float_as_int(st.hit[seg_base + i0 + threadIdx.x].y);
+                if (hid >= 0) key = (__float_as_int(S.faces[(size_t)hid * PT_FACE_F4].x) >> 28) & 3;
+            }
+            const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2);
+            if (lane == 0) { sh_key[0][wave] = __popcll(m0); sh_key[1][wave] = __popcll(m1); sh_key[2][wave] = __popcll(m2); }
+            __syncthreads();
+            int before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+#pragma unroll
+            for (int w = 0; w < PT_BLOCK / 64; w++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int cnt = sh_key[k][w]; if (w < wave) before[k] += cnt; total[k] += cnt; }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int r0_ = __popcll(m0 & below), r1_ = __popcll(m1 & below), r2_ = __popcll(m2 & below);
+            // class 3 takes what is left, in workgroup order: my index minus the lanes of classes 0..2 before me
+            const int before_all = before[0] + before[1] + before[2] + r0_ + r1_ + r2_;
+            int pos = total[0] + total[1] + total[2] + ((int)threadIdx.x - before_all);
+            pos = (key == 2) ? total[0] + total[1] + before[2] + r2_ : pos;
+            pos = (key == 1) ? total[0] + before[1] + r1_ : pos;
+            pos = (key == 0) ? before[0] + r0_ : pos;
+            sh_perm[pos] = (unsigned char)threadIdx.x;
+            __syncthreads();
+            src = sh_perm[threadIdx.x];
+        }
+        const int i = i0 + src;
         const bool valid = i < n;
         bool cont = false, shadow = false, pending = false;
         bool ev_miss = false, ev_rr = false, ev_emit = false, ev_pdf = false, ev_limit = false;
@@ -1508,8 +1544,14 @@ __global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__re
 // ------------------------------------------------------------------------------------------------
 // emitted() of whatever a shadow ray hit, times the stored coefficient (integrator.h:252-262).  The emitted radiance
 // comes from one table load by hit id; non-emitters contribute (coef*0)/pick = +-0 or NaN, i.e. nothing.
+// v / (float)n for a small positive count n (lights, light samples).  For n a power of two the quotient is v * (1 / n)
+// bit for bit -- both are the correctly rounded value of the same real number, 1 / n is exact -- which spares three IEEE
+// divisions per call (one light, four light samples: every BASELINE configuration).
+struct CountDiv { float d, inv; bool pow2; };
+DEVI CountDiv count_div(int n) { CountDiv c; c.d = (float)n; c.inv = 1.0f / (float)n; c.pow2 = n > 0 && (n & (n - 1)) == 0; return c; }
+DEVI v3 vdiv_count(v3 v, const CountDiv &c) { return c.pow2 ? vscale(c.inv, v) : vdivf(v, c.d); }
 template <bool TEX>
-DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id, v3 coef, float pick_pdf, v3 &lc)
+DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id, v3 coef, const CountDiv &pick_pdf, v3 &lc)
 {
     if (id < 0) return;
     const float4 e = S.emit[id];
@@ -1520,7 +1562,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
     }
     if (le.x == 0.0f && le.y == 0.0f && le.z == 0.0f) return;
     v3 c = vmul(coef, le);
-    c = vdivf(c, pick_pdf);
+    c = vdiv_count(c, pick_pdf);
     if (!v_is_nan(c)) lc = vadd(lc, c);
 }
 
@@ -1541,7 +1583,8 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S,
     const uint32_t L = (uint32_t)S.light_samples, NV = (uint32_t)S.n_vol;
     const uint32_t D = NV + L * (3u + NV) + 4u;
     const uint32_t base = DIM_BOUNCE0 + (uint32_t)bounce * D;
-    const float pick_pdf = (float)S.n_lights;   // integrator.h:224
+    const CountDiv pick_pdf = count_div(S.n_lights);   // integrator.h:224
+    const CountDiv n_samples = count_div(S.light_samples);
     unsigned long long n_rays = 0;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
         const int chunk = c / b.n_seg_out, seg = c - chunk * b.n_seg_out;   // chunk-major, see k_extend
@@ -1596,7 +1639,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S,
         if (valid) {
             const int slot = slotw & 0x7fffffff;
             const float4 rad = st.radiance[slot];
-            v3 r = vadd(V(rad.x, rad.y, rad.z), vdivf(lc, (float)S.light_samples));   // integrator.h:268
+            v3 r = vadd(V(rad.x, rad.y, rad.z), vdiv_count(lc, n_samples));   // integrator.h:268
             if (slotw < 0) { const float4 pe = st.pending[slot]; r = vadd(r, V(pe.x, pe.y, pe.z)); }
             st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
         }
