@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
@@ -189,6 +189,28 @@ int pt_read_last_batch_radiance(pt_ctx *ctx, float *rgba, size_t max_records, si
  * t and id = instance*8 + face, or -1 for a miss. */
 int pt_trace_rays(pt_ctx *ctx, int64_t n, int32_t rays_per_origin, const float *origins, const float *dirs,
                   uint32_t k0, uint32_t k1, uint32_t vol_dim, float *t_out, int32_t *id_out);
+
+/* ---- multi-GPU in one process ------------------------------------------------------------
+ * One context per listed device (an ordinal may repeat: two contexts on one GPU rehearse the path on a one-GPU box).
+ * The film is cut into block_w x block_h tiles in NaiveSpiral order (queue.h:68-127) and every tile is owned by one
+ * device (cost-balanced over measured per-tile ray counts; PATHTRACE_HIP_ROUND_ROBIN=1: tile k -> device k mod n);
+ * pt_multi_render_async enqueues each device's tiles as wavefront batches and returns, there is no communication while
+ * rendering, and reading the framebuffer sums the per-device framebuffers into the first device -- device-to-device
+ * copies + an add kernel, or one RCCL ncclReduce per device (PATHTRACE_HIP_MULTI_RCCL=1).  The result is the
+ * single-device image bit for bit.  Replaces the thread fan-out of Tiled::start_render (renderer.h:553-603). */
+typedef struct pt_multi pt_multi;
+pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, int32_t n_devices, const int32_t *devices,
+                          int32_t block_w, int32_t block_h);
+void pt_multi_destroy(pt_multi *m);
+int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp_end);
+int pt_multi_poll(pt_multi *m, uint64_t *samples_done, uint64_t *rays_done);      /* 1 done, 0 running, < 0 error */
+int pt_multi_wait(pt_multi *m);
+int pt_multi_read_framebuffer(pt_multi *m, float *rgb_sum);                        /* height*width*3, row 0 = bottom row */
+int pt_multi_snapshot_framebuffer(pt_multi *m, float *rgb_sum, uint64_t *samples_accumulated);
+int pt_multi_get_counters(pt_multi *m, pt_counters *out);                          /* summed over the devices */
+int pt_multi_clear(pt_multi *m);
+int pt_multi_device_count(pt_multi *m);
+int pt_multi_tile_owners(pt_multi *m, int32_t *owners, int32_t max_tiles);         /* owner index per spiral tile; returns the tile count */
 
 const char *pt_last_error(void);
 int pt_abi_version(void);

@@ -102,6 +102,9 @@ EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async"
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
+           "pt_multi_create", "pt_multi_destroy", "pt_multi_render_async", "pt_multi_poll", "pt_multi_wait",
+           "pt_multi_read_framebuffer", "pt_multi_snapshot_framebuffer", "pt_multi_get_counters", "pt_multi_clear",
+           "pt_multi_device_count", "pt_multi_tile_owners",
            "pth_config_from_file", "pth_config_from_json", "pth_scene_from_file", "pth_scene_from_json",
            "pth_scene_desc", "pth_scene_free", "pth_spiral_tiles", "pth_write_ppm", "pth_main"]
 
@@ -140,6 +143,19 @@ def lib():
     L.pt_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     L.pt_read_last_batch_radiance.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pt_trace_rays.argtypes = [vp, C.c_int64, C.c_int32, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_int32)]
+    L.pt_multi_create.restype = vp
+    L.pt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(Config), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+    L.pt_multi_destroy.argtypes = [vp]
+    L.pt_multi_destroy.restype = None
+    L.pt_multi_render_async.argtypes = [vp, C.c_int32, C.c_int32]
+    L.pt_multi_poll.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pt_multi_wait.argtypes = [vp]
+    L.pt_multi_read_framebuffer.argtypes = [vp, fp]
+    L.pt_multi_snapshot_framebuffer.argtypes = [vp, fp, C.POINTER(C.c_uint64)]
+    L.pt_multi_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.pt_multi_clear.argtypes = [vp]
+    L.pt_multi_device_count.argtypes = [vp]
+    L.pt_multi_tile_owners.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
     L.pt_last_error.restype = C.c_char_p
     L.pt_abi_version.restype = C.c_int
     L.pt_device_count.restype = C.c_int
@@ -357,6 +373,68 @@ class Renderer:
 
     def set_stream(self, ptr):
         _check(lib().pt_set_stream(self._h, ptr), "pt_set_stream")
+
+
+class MultiRenderer:
+    """pt_multi: one context per listed device in this process, tiles cost-balanced over them, one sum at the end."""
+
+    def __init__(self, scene: Scene, devices, max_bounces=10, light_samples=4, russian_roulette=True, only_direct=False,
+                 normal_offset=1e-4, seed=0, max_paths_in_flight=0, block=128):
+        self.scene = scene
+        self.width, self.height = scene.width, scene.height
+        self.cfg = Config(self.width, self.height, max_bounces, light_samples, int(russian_roulette), int(only_direct),
+                          np.float32(normal_offset), seed, -1, max_paths_in_flight)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        self._h = lib().pt_multi_create(C.byref(scene.desc), C.byref(self.cfg), len(devices), devs, block, block)
+        if not self._h:
+            raise PathtraceError(f"pt_multi_create failed: {last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_async(self, spp_begin, spp_end):
+        _check(lib().pt_multi_render_async(self._h, spp_begin, spp_end), "pt_multi_render_async")
+
+    def wait(self):
+        _check(lib().pt_multi_wait(self._h), "pt_multi_wait")
+
+    def poll(self):
+        s, r = C.c_uint64(), C.c_uint64()
+        done = _check(lib().pt_multi_poll(self._h, C.byref(s), C.byref(r)), "pt_multi_poll")
+        return bool(done), s.value, r.value
+
+    def framebuffer(self) -> np.ndarray:
+        fb = np.zeros((self.height, self.width, 3), np.float32)
+        _check(lib().pt_multi_read_framebuffer(self._h, fb.ctypes.data_as(C.POINTER(C.c_float))), "pt_multi_read_framebuffer")
+        return fb
+
+    def snapshot(self):
+        fb = np.zeros((self.height, self.width, 3), np.float32)
+        n = C.c_uint64()
+        _check(lib().pt_multi_snapshot_framebuffer(self._h, fb.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)), "pt_multi_snapshot_framebuffer")
+        return fb, n.value
+
+    def counters(self) -> dict:
+        c = Counters()
+        _check(lib().pt_multi_get_counters(self._h, C.byref(c)), "pt_multi_get_counters")
+        return c.as_dict()
+
+    def clear(self):
+        _check(lib().pt_multi_clear(self._h), "pt_multi_clear")
+
+    def tile_owners(self):
+        n = lib().pt_multi_tile_owners(self._h, None, 0)
+        buf = (C.c_int32 * n)()
+        lib().pt_multi_tile_owners(self._h, buf, n)
+        return list(buf)
 
 
 def write_ppm(path, fb_sum: np.ndarray, samples: int, exposure_field: float = 2.2):

@@ -16,10 +16,12 @@ LIB = os.path.join(LIB_DIR, "libpathtrace_hip.so")
 SOURCES = [
     os.path.join(CSRC, "device", "pt_kernels.hip"),
     os.path.join(CSRC, "device", "pt_context.cpp"),
+    os.path.join(CSRC, "device", "pt_multi.cpp"),
     os.path.join(CSRC, "host", "pt_host.cpp"),
 ]
 HEADERS = [
     os.path.join(CSRC, "device", "pt_device.h"),
+    os.path.join(CSRC, "device", "pt_fdiv.h"),
     os.path.join(CSRC, "host", "json_min.h"),
     os.path.join(HERE, "..", "include", "pathtrace_hip.h"),
 ]
@@ -27,7 +29,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 mul/add into v_pk_*_f32, whose SGPR operands must be
 # aligned pairs -- every packed op then costs two s_mov on the (single per CU) scalar unit and extra VGPRs.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-ldl"]
 
 
 def needs_build() -> bool:

@@ -22,8 +22,9 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s);
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
-void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
+void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s);
+int launch_grid_max();
 }  // namespace ptd
 
 using namespace ptd;
@@ -81,7 +82,8 @@ struct pt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;   // lane 0's stream (stream may be caller-owned)
     hipEvent_t done_ev = nullptr;
     Lane lanes[PT_MAX_LANES];
-    int n_lanes = 1;
+    int n_lanes = 1;                 // lanes batches are scheduled on
+    int n_lanes_alloc = 1;           // lanes that own streams / events / buffers (teardown, synchronisation)
     int next_lane = 0;
     int last_lane = -1;              // lane of the most recent batch (its acc_done orders the next accumulate)
     int last_batch_lane = 0;
@@ -189,7 +191,13 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
                 op.kind = OP_LEAF_VOLBOX;
                 memcpy(op.g, bd.p0, 12); memcpy(op.g + 3, bd.p1, 12);
                 op.g[6] = p.density;
-            } else return -2;   // only box boundaries (the reference's volume scenes); refused loudly by the caller
+            } else if (bd.type == PT_PRIM_SPHERE) {
+                op.kind = OP_LEAF_VOLSPHERE;
+                memcpy(op.g, bd.center, 12); op.g[3] = bd.radius;
+                op.g[6] = p.density;
+            } else if (bd.type == PT_PRIM_RECT) {
+                op.kind = OP_LEAF_NONE;
+            } else return -2;   // a medium inside a medium: refused loudly by the caller
             break;
         }
         default: return -1;
@@ -438,16 +446,15 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             }
     int pending_push = -1;
     if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) {
-        set_err("pt_create: malformed BVH, or a volume whose boundary is not a box (only box boundaries are implemented "
-                "on the device: the reference's volume scenes use nothing else)");
+        set_err("pt_create: malformed BVH, or a constant_medium whose boundary is another constant_medium");
         return -1;
     }
-    if (max_depth > PT_MAX_STACK) {
-        set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds %d", max_depth, PT_MAX_STACK);
+    if (max_depth > 64) {
+        set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds 64", max_depth);
         return -1;
     }
     for (DOp &op : ops)
-        if (op.kind == OP_LEAF_VOLBOX) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
+        if (op.kind == OP_LEAF_VOLBOX || op.kind == OP_LEAF_VOLSPHERE) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
     if (ops.size() >= (1u << 22)) { set_err("pt_create: traversal program too long (%zu ops)", ops.size()); return -1; }
     ops.push_back(DOp{});   // padding op (never executed)
     // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
@@ -499,7 +506,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         return -1;
     S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
     S.geom_all = 0;
-    for (const DOp &op : ops) S.geom_all |= (op.kind == OP_LEAF_SPHERE || op.kind == OP_LEAF_VOLBOX);
+    for (const DOp &op : ops) S.geom_all |= (op.kind >= OP_LEAF_SPHERE);
     {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_n): every leaf's linear part is
         // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
         // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  Scenes outside it (or
@@ -519,7 +526,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             }
             if (op.kind < OP_LEAF_RECT_XY) continue;
             for (int i = 0; i < 12; i++) S.tame &= in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13) ? 1 : 0;
-            const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : 6;   // rect x0 z0 x1 z1 y; box / volume p0 p1; sphere: IEEE divisions
+            const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : ((op.kind == OP_LEAF_BOX || op.kind == OP_LEAF_VOLBOX) ? 6 : 0);   // rect x0 z0 x1 z1 y; box p0 p1; spheres divide the IEEE way
             for (int i = 0; i < np; i++) S.tame &= in_range(op.g[i], -20, 20) ? 1 : 0;
         }
     }
@@ -551,6 +558,16 @@ static int alloc_streams(pt_ctx *c)
 {
     int64_t want = c->cfg.max_paths_in_flight > 0 ? c->cfg.max_paths_in_flight : (int64_t)8 << 20;
     want = std::max<int64_t>(want, 64);
+    // a path slot travels as an int32 whose bit 31 is the `pending` flag (k_shade / k_connect), segment counts and pixel
+    // counts are int32: refuse what would overflow them instead of corrupting slot ids
+    if (want > ((int64_t)1 << 30)) {
+        set_err("pt_create: max_paths_in_flight = %lld exceeds 2^30 path slots per batch", (long long)want);
+        return -1;
+    }
+    if ((int64_t)c->cfg.width * c->cfg.height > ((int64_t)1 << 30)) {
+        set_err("pt_create: film of %d x %d pixels exceeds 2^30", c->cfg.width, c->cfg.height);
+        return -1;
+    }
     c->seg_cap = 4096;   // measured on cornell_box 1080p: 1024 -2.4 %, 2048 -1.4 %, 4096 best, 8192 / 16384 -0.3 %
     if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) c->seg_cap = v; }
     c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
@@ -563,9 +580,11 @@ static int alloc_streams(pt_ctx *c)
     if (dev_alloc(c, &ctr, PT_COUNTER_BANKS)) return -1;
     HIP_TRY(hipMemset(c->fb_own, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
     HIP_TRY(hipMemset(ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS));
-    // small renders (a few batches at most) do not need the extra lanes' memory
+    // every lane owns a full set of stream buffers (P slots, 288 B each at light_samples = 4); 2 lanes measured best
+    // (1: the thin late bounces are exposed, 3: +2 %, 4: no further gain)
     const char *env = getenv("PATHTRACE_HIP_LANES");
-    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 2;   // 2 measured best (1: tails exposed, 4: no gain)
+    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 2;
+    c->n_lanes_alloc = c->n_lanes;
     for (int l = 0; l < c->n_lanes; l++) {
         Lane &ln = c->lanes[l];
         DStreams &st = ln.st;
@@ -578,6 +597,12 @@ static int alloc_streams(pt_ctx *c)
             dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
             return -1;
         if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
+        st.gstack = nullptr;
+        st.gstack_stride = 0;
+        if (c->S.stack_depth > PT_MAX_STACK) {   // deeper than the LDS short stack: a global one per lane (kernels of two lanes overlap)
+            st.gstack_stride = launch_grid_max() * 256;
+            if (dev_alloc(c, &st.gstack, (size_t)c->S.stack_depth * 4 * (size_t)st.gstack_stride)) return -1;
+        }
         st.fb = c->fb_own;
         st.counters = ctr;
         if (l == 0) ln.stream = c->own_stream;
@@ -622,9 +647,9 @@ extern "C" void pt_destroy(pt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (int l = 0; l < c->n_lanes; l++)
+    for (int l = 0; l < c->n_lanes_alloc; l++)
         if (c->lanes[l].stream) (void)hipStreamSynchronize(c->lanes[l].stream);
-    for (int l = 0; l < c->n_lanes; l++) {
+    for (int l = 0; l < c->n_lanes_alloc; l++) {
         if (c->lanes[l].acc_done) (void)hipEventDestroy(c->lanes[l].acc_done);
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
     }
@@ -812,7 +837,7 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
     const bool same = table.size() == c->h_tiles.size() &&
                       (table.empty() || memcmp(table.data(), c->h_tiles.data(), table.size() * sizeof(DTile)) == 0);
     if (!same) {
-        for (int l = 0; l < c->n_lanes; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));   // old table may be in use
+        for (int l = 0; l < c->n_lanes_alloc; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));   // old table may be in use
         if (table.size() > c->d_tiles_cap) {
             if (dev_alloc(c, &c->d_tiles, table.size() * 2)) return -1;
             c->d_tiles_cap = table.size() * 2;
@@ -877,7 +902,7 @@ static int collect_times(pt_ctx *c)
 extern "C" int pt_wait(pt_ctx *c)
 {
     if (!c) { set_err("pt_wait: null ctx"); return -1; }
-    for (int l = 0; l < c->n_lanes; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
+    for (int l = 0; l < c->n_lanes_alloc; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
     return collect_times(c);
 }
 
@@ -961,7 +986,7 @@ extern "C" int pt_trace_rays(pt_ctx *c, int64_t n, int32_t nr, const float *orig
             hipMalloc((void **)&d_t, nray * 4) != hipSuccess || hipMalloc((void **)&d_i, nray * 4) != hipSuccess) { set_err("pt_trace_rays: hipMalloc failed"); break; }
         if (hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_d, dirs, nray * 12, hipMemcpyHostToDevice) != hipSuccess) { set_err("pt_trace_rays: upload failed"); break; }
-        launch_trace(c->S, n, nr, d_o, d_d, k0, k1, vol_dim, d_t, d_i, c->stream);
+        launch_trace(c->S, c->lanes[0].st, n, nr, d_o, d_d, k0, k1, vol_dim, d_t, d_i, c->stream);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { set_err("pt_trace_rays: kernel failed"); break; }
         if (hipMemcpy(t_out, d_t, nray * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(id_out, d_i, nray * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("pt_trace_rays: download failed"); break; }
@@ -990,10 +1015,13 @@ extern "C" int pt_set_stream(pt_ctx *c, void *s)
 {
     if (!c) { set_err("pt_set_stream: null ctx"); return -1; }
     if (pt_wait(c)) return -1;
-    // a caller-owned stream means the caller orders the work: run everything on it, one lane
+    // a caller-owned stream means the caller orders the work: run everything on it, one lane; handing the stream back
+    // (NULL) restores the context's own lanes.  pt_wait above left every lane idle, so no batch order is pending.
     c->stream = s ? (hipStream_t)s : c->own_stream;
     c->lanes[0].stream = c->stream;
-    if (s) { c->n_lanes = 1; c->next_lane = 0; }
+    c->n_lanes = s ? 1 : c->n_lanes_alloc;
+    c->next_lane = 0;
+    c->last_lane = -1;
     return 0;
 }
 extern "C" int pt_set_profiling(pt_ctx *c, int enabled)

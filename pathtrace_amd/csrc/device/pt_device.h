@@ -76,6 +76,9 @@ enum {
     OP_LEAF_BOX = 5,     // f[0..11] inverse, f[12..14] = p0, f[15..17] = p1              (primitive.h:229-242)
     OP_LEAF_SPHERE = 6,  // f[0..11] inverse, f[12..14] = center, f[15] = radius
     OP_LEAF_VOLBOX = 7,  // constant_medium with a box boundary: as OP_LEAF_BOX + f[18] = density, f[19] = bits(vol_ord)
+    OP_LEAF_VOLSPHERE = 8, // constant_medium with a sphere boundary: as OP_LEAF_SPHERE + f[18] = density, f[19] = bits(vol_ord)
+    OP_LEAF_NONE = 9,    // a leaf that never reports a hit: constant_medium whose boundary is a rect (its second boundary hit
+                         // beyond t1 + 0.0001 cannot exist, or both are NaN and the medium test fails: volume.h:33-46, 70-75)
 };
 struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in the device array
     // first half: everything an op needs FIRST (header + node box or instance matrix)
@@ -184,6 +187,9 @@ struct DStreams {
     float4 *pending;             // [P]: second emitter addition (integrator.h:319), applied by connect
     float4 *fb;                  // [height*width] rgba framebuffer SUM
     DCounters *counters;         // [PT_COUNTER_BANKS]
+    float2 *gstack;              // general sweep's short stack for trees deeper than PT_MAX_STACK: [slot][ray <= 4][gstack_stride
+    int32_t gstack_stride;       // threads], NULL while the LDS stack suffices (pt_kernels.hip stack_of)
+    int32_t pad_;
 };
 
 }  // namespace ptd

@@ -16,8 +16,9 @@
 //    and arrive through scalar loads into SGPRs; lanes that missed an enclosing box are masked off until
 //    the op where that subtree ends.  The per-lane short stack of partial results lives in LDS,
 //    [slot][lane] so that consecutive lanes hit consecutive banks.
-//  * Queues are segmented per workgroup (pt_device.h): compaction = wave ballot + popcount prefix + a
-//    4-entry LDS scan, no global atomics, deterministic order.
+//  * Queues are segmented (pt_device.h): compaction = wave ballot + popcount prefix + a 4-entry LDS scan, then ONE
+//    atomicAdd per workgroup and queue on the output segment's counter.  Queue order is therefore not deterministic;
+//    per-path arithmetic does not depend on it, and k_accumulate adds a pixel's samples in sample order.
 //  * All streams are float4 / float2 planes indexed by queue position: each wave-level load or store is
 //    one fully coalesced 1 KiB / 512 B transaction.
 #include <hip/hip_runtime.h>
@@ -241,6 +242,35 @@ DEVI bool sphere_hit_t(const DPrim &s, v3 A, v3 B, float t_min, float t_max, flo
     }
     return false;
 }
+// sphere::hit primitive.h:64-95 on the local ray, oc = origin - center, c = dot(oc, oc) - radius^2
+DEVI bool sphere_t(v3 oc, float c, v3 Bl, float t_min, float t_max, float &t_out)
+{
+    const float a = vdot(Bl, Bl);
+    const float b = vdot(oc, Bl);
+    const float disc = b * b - a * c;
+    if (disc > 0) {
+        float temp = (-b - sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) { t_out = temp; return true; }
+        temp = (-b + sqrtf(disc)) / a;
+        if (temp < t_max && temp > t_min) { t_out = temp; return true; }
+    }
+    return false;
+}
+// constant_medium::hit volume.h:29-93 once both boundary hits are known (hit1 / hit2 with t1v, t2v): clamp, free-flight
+// distance from one draw, inside test.  Returns the hit and its t.
+DEVI bool medium_decide(bool hit, float t1v, float t2v, v3 Bl, float density, float u, float &t_out)
+{
+    const float T_MIN = 0.001f, T_MAX = FLT_MAX;
+    t1v = (t1v < T_MIN) ? T_MIN : t1v;
+    t2v = (t2v > T_MAX) ? T_MAX : t2v;
+    hit = hit && !(t1v >= t2v);
+    t1v = (t1v < 0) ? 0.0f : t1v;
+    const float dlen = vlen(Bl);
+    const float distance_inside = (t2v - t1v) * dlen;
+    const float hit_distance = (-(1 / density)) * ptm_logf(u);
+    t_out = t1v + hit_distance / dlen;
+    return hit && (hit_distance < distance_inside);
+}
 // ---- leaf tests on NR rays that share one origin (NR = 1: extension ray; NR = light_samples: the shadow rays of
 // one hit).  The local origin (ray::apply ray.h:20-24) and every numerator that depends only on it are computed
 // once; each ray's own arithmetic is exactly the single-ray sequence.
@@ -326,6 +356,17 @@ DEVI void box_hit_fast(const float *p0, const float *p1, v3 Al, v3 Bl, float t0,
     face = f;
 }
 
+// The general sweep's short stack of partial results, [slot][ray][thread]: in LDS (stride PT_BLOCK) while the tree needs at
+// most PT_MAX_STACK slots, else in a global scratch area of the launching lane (DStreams::gstack; stride = threads of
+// the largest grid).  One pointer type for both: the few waves that take the general sweep use flat loads / stores.
+struct Stk { float2 *p; int stride; };
+DEVI Stk stack_of(const DStreams &st, float2 *lds)
+{
+    Stk k;
+    if (st.gstack) { k.p = st.gstack + ((size_t)blockIdx.x * PT_BLOCK + threadIdx.x); k.stride = st.gstack_stride; }
+    else { k.p = lds + threadIdx.x; k.stride = PT_BLOCK; }
+    return k;
+}
 // ------------------------------------------------------------------------------------------------
 // World::hit (world.h:17-20 -> bvh.h:31-69 -> primitive.h:298-312) as a lock-step sweep over NR rays per lane
 // that share the origin A.  Returns per ray id = -1 (miss) or instance*8 + face, and t.  `stk` points at this
@@ -346,7 +387,7 @@ DEVI void box_hit_fast(const float *p0, const float *p1, v3 Al, v3 Bl, float t0,
 // world_hit_fast below instead (world_hit picks).
 template <int NR, bool GA>
 DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
-                      const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR], bool all_finite)
+                      const uint32_t (&vol_dim_base)[NR], Stk stk, float (&out_t)[NR], int (&out_id)[NR], bool all_finite)
 {
     const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
     v3 inv[NR];
@@ -372,7 +413,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
 #define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
         if (op_push >= 0) {
 #pragma unroll
-            for (int r = 0; r < NR; r++) stk[(op_push * NR + r) * PT_BLOCK] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
+            for (int r = 0; r < NR; r++) stk.p[(size_t)(op_push * NR + r) * stk.stride] = make_float2(cur_t[r], __int_as_float(cur_id[r]));
         }
         if (kind == OP_ENTER) {
             // aabb::hit aabb.h:34-53; (min - origin), (max - origin) are shared by the NR rays.
@@ -410,7 +451,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
         } else if (kind == OP_COMBINE) {   // bvh.h:36-66: left iff left.hit && (!right.hit || left.t < right.t)
 #pragma unroll
             for (int r = 0; r < NR; r++) {
-                const float2 l = stk[(op_slot * NR + r) * PT_BLOCK];
+                const float2 l = stk.p[(size_t)(op_slot * NR + r) * stk.stride];
                 const int lid = (pc >= skip[r]) ? __float_as_int(l.y) : -1;   // a masked ray keeps its -1
                 const int lt = (l.x < cur_t[r]) ? -1 : 0;
                 const int take = (~(lid >> 31)) & ((cur_id[r] >> 31) | lt);    // all-ones iff take left
@@ -492,6 +533,23 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     cur_id[r] = hit ? op_id_base : -1;
                     cur_t[r] = hit ? (ha ? ta : tb) : cur_t[r];
                 }
+            } else if (GA && kind == OP_LEAF_VOLSPHERE) {   // constant_medium::hit volume.h:29-93 with a sphere boundary
+                const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+                const float c = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = XF_DIR(B[r]);
+                    float t1v = 0.0f, t2v = 0.0f, tv;
+                    bool hit = sphere_t(oc, c, Bl, -FLT_MAX, FLT_MAX, t1v);
+                    hit = hit && sphere_t(oc, c, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v);
+                    const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
+                    hit = medium_decide(hit, t1v, t2v, Bl, OPF(18), u, tv) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? tv : cur_t[r];
+                }
+            } else {   // OP_LEAF_NONE (and kinds this instantiation does not carry): the leaf reports a miss
+#pragma unroll
+                for (int r = 0; r < NR; r++) cur_id[r] = -1;
             }
         }
 #undef XF_DIR
@@ -686,6 +744,20 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 const float ts = ha ? ta : tb;
                 FOLD(r, ((disc > 0) && (ha || hb)) ? 0.0f : 1.0f, ts, op_id_base)
             }
+        } else if (GA && kind == OP_LEAF_VOLSPHERE) {   // constant_medium::hit volume.h:29-93 with a sphere boundary
+            const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+            const float c = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float t1v = 0.0f, t2v = 0.0f, tv;
+                bool hit = sphere_t(oc, c, Bl[r], -FLT_MAX, FLT_MAX, t1v);
+                hit = hit && sphere_t(oc, c, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v);
+                chk = __builtin_fmaf(0.0f, t1v, chk);
+                chk = __builtin_fmaf(0.0f, t2v, chk);
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
+                hit = medium_decide(hit, t1v, t2v, Bl[r], OPF(18), u, tv);
+                FOLD(r, hit ? 0.0f : 1.0f, tv, op_id_base)
+            }
         }
 #undef FOLD
 #undef OPF
@@ -698,7 +770,7 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
 // World::hit for NR rays of one origin: picks the sweep for this wave (wave-uniform, one scalar branch).
 template <int NR, bool GA>
 DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
-                    const uint32_t (&vol_dim_base)[NR], float2 *stk, float (&out_t)[NR], int (&out_id)[NR])
+                    const uint32_t (&vol_dim_base)[NR], Stk stk, float (&out_t)[NR], int (&out_id)[NR])
 {
     // tame: A components zero or 2^-20 <= |x| <= 2^20, B components 2^-20 <= |x| <= 2^20 (non-zero); implies finite
     bool tame = fdiv_in_range(A.x, -20, 20) && fdiv_in_range(A.y, -20, 20) && fdiv_in_range(A.z, -20, 20);
@@ -1093,6 +1165,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][1][PT_BLOCK]
+    const Stk stk = stack_of(st, stack);
     // Persistent workgroups: a launch has at most a few thousand workgroups (dispatching a 256-thread workgroup costs
     // 3-15 ns of serial dispatcher time on MI355X, which dominated the thin late bounces when every chunk was its own
     // workgroup), and each strides over the 256-lane chunks of the segmented queue; empty chunks cost one scalar load.
@@ -1132,7 +1205,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
-        world_hit<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, &stack[threadIdx.x], t, id);
+        world_hit<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0 && n_rays) {
@@ -1575,6 +1648,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S,
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
     extern __shared__ float2 stack[];   // [stack_depth][max(NR,1)][PT_BLOCK]
+    const Stk stk = stack_of(st, stack);
     // the shadow queue was written by this bounce's shade in the OUTPUT segmentation
     const int cps = b.seg_cap_out / PT_BLOCK;
     const int total_chunks = b.n_seg_out * cps;
@@ -1618,7 +1692,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S,
                     coef[k] = V(d.w, e.x, e.y);
                     vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
                 }
-                world_hit<R, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit<R, GA>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
@@ -1632,7 +1706,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S,
                 const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
                 float t[1];
                 int id[1];
-                world_hit<1, GA>(S, valid, hp, ldir, k0, k1, vd, &stack[threadIdx.x], t, id);
+                world_hit<1, GA>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
                 if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
@@ -1675,29 +1749,32 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 // trace: World::hit for caller-supplied rays (pt_trace_rays), same traversal as k_extend / k_connect
 // ------------------------------------------------------------------------------------------------
 template <int NR, bool GA>
-__global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restrict__ t_ops, long long n, const float *__restrict__ org,
+__global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restrict__ t_ops, DStreams st, long long n, const float *__restrict__ org,
                                                     const float *__restrict__ dir, uint32_t k0, uint32_t k1, uint32_t vol_dim,
                                                     float *t_out, int *id_out)
 {
     S.ops = t_ops;
     extern __shared__ float2 stack[];
-    const long long i = (long long)blockIdx.x * PT_BLOCK + threadIdx.x;
-    const bool valid = i < n;
-    const long long j = valid ? i : 0;
-    const v3 A = V(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
-    v3 B[NR];
-    uint32_t vd[NR];
-    float t[NR];
-    int id[NR];
+    const Stk stk = stack_of(st, stack);
+    for (long long base = (long long)blockIdx.x * PT_BLOCK; base < n; base += (long long)gridDim.x * PT_BLOCK) {   // bounded grid: the
+        const long long i = base + threadIdx.x;                                                                   // global stack is per thread
+        const bool valid = i < n;
+        const long long j = valid ? i : 0;
+        const v3 A = V(org[3 * j], org[3 * j + 1], org[3 * j + 2]);
+        v3 B[NR];
+        uint32_t vd[NR];
+        float t[NR];
+        int id[NR];
 #pragma unroll
-    for (int r = 0; r < NR; r++) {
-        B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
-        vd[r] = vol_dim + (uint32_t)r * 16u;
-    }
-    world_hit<NR, GA>(S, valid, A, B, k0, k1, vd, &stack[threadIdx.x], t, id);
-    if (valid) {
+        for (int r = 0; r < NR; r++) {
+            B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
+            vd[r] = vol_dim + (uint32_t)r * 16u;
+        }
+        world_hit<NR, GA>(S, valid, A, B, k0, k1, vd, stk, t, id);
+        if (valid) {
 #pragma unroll
-        for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }
+            for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }
+        }
     }
 }
 
@@ -1717,7 +1794,7 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 }
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    const size_t lds = (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
+    const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
     if (S.geom_all) hipLaunchKernelGGL(k_extend<true>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
     else hipLaunchKernelGGL(k_extend<false>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
 }
@@ -1738,7 +1815,7 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     static const int force = getenv("PATHTRACE_HIP_CONNECT_NR") ? atoi(getenv("PATHTRACE_HIP_CONNECT_NR")) : 0;
     int nr = (L % 2 == 0) ? 2 : 1;
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
-    const size_t lds = (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
+    const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
 #define PT_LAUNCH_CONNECT(NR, TEX, GA) hipLaunchKernelGGL((k_connect<NR, TEX, GA>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
 #define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA); else PT_LAUNCH_CONNECT(1, TEX, GA); }
@@ -1747,15 +1824,30 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
 #undef PT_LAUNCH_CONNECT_NR
 #undef PT_LAUNCH_CONNECT
 }
-void launch_trace(const DScene &S, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
+void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s)
 {
-    const int blocks = (int)((n + PT_BLOCK - 1) / PT_BLOCK);
-    const size_t lds = (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
-#define PT_LAUNCH_TRACE(NR, GA) hipLaunchKernelGGL((k_trace<NR, GA>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, n, org, dir, k0, k1, vol_dim, t_out, id_out)
+    const int blocks = persistent_grid((n + PT_BLOCK - 1) / PT_BLOCK);
+    const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
+#define PT_LAUNCH_TRACE(NR, GA) hipLaunchKernelGGL((k_trace<NR, GA>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, st, n, org, dir, k0, k1, vol_dim, t_out, id_out)
     if (S.geom_all) { if (nr == 4) PT_LAUNCH_TRACE(4, true); else if (nr == 2) PT_LAUNCH_TRACE(2, true); else PT_LAUNCH_TRACE(1, true); }
     else { if (nr == 4) PT_LAUNCH_TRACE(4, false); else if (nr == 2) PT_LAUNCH_TRACE(2, false); else PT_LAUNCH_TRACE(1, false); }
 #undef PT_LAUNCH_TRACE
+}
+int launch_grid_max() { return persistent_grid(1ll << 40); }
+// multi-GPU reduce on the root device (pt_multi.cpp): dst += src over RGBA framebuffers whose tiles are disjoint
+__global__ __launch_bounds__(PT_BLOCK) void k_add_fb(float4 *__restrict__ dst, const float4 *__restrict__ src, long long n)
+{
+    for (long long i = (long long)blockIdx.x * PT_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * PT_BLOCK) {
+        const float4 a = dst[i], b = src[i];
+        dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+void launch_add_fb(void *dst_rgba, const void *src_rgba, long long n_pixels, hipStream_t s)
+{
+    long long blocks = (n_pixels + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_add_fb, dim3((int)blocks), dim3(PT_BLOCK), 0, s, (float4 *)dst_rgba, (const float4 *)src_rgba, n_pixels);
 }
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {

@@ -1,0 +1,325 @@
+// Multi-GPU inside the library (include/pathtrace_hip.h pt_multi_*): one pt_ctx per device in ONE process,
+// the film partitioned by image tile in NaiveSpiral order (queue.h:68-127), every device renders its tiles with no
+// communication, and one exchange at the end sums the framebuffers into the first device.  Tile ownership is disjoint,
+// so every pixel receives one non-zero term and the image is the single-device image bit for bit, for any device list.
+//
+// The reference's analogue is the thread fan-out of Tiled::start_render (renderer.h:553-603): config.threads workers
+// pulling tiles from one spiral queue into one shared framebuffer.  Here the "workers" are GPUs, the queue is a static
+// cost-balanced ownership map (a GPU batches all its tiles into one wavefront launch, so tiles cannot be pulled one at
+// a time), and the shared framebuffer is reassembled by the final sum.
+//
+// Exchange: device-to-device copies of each peer's framebuffer into a staging buffer on the root plus an add kernel
+// (default: each peer has its own xGMI link to the root, and it also works when one device is listed twice), or one
+// RCCL ncclReduce per device in a group (PATHTRACE_HIP_MULTI_RCCL=1; librccl.so is loaded on demand, the library does
+// not link it).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../../include/pathtrace_hip.h"
+
+void pth_set_error(const std::string &m);
+namespace ptd {
+void launch_add_fb(void *dst_rgba, const void *src_rgba, long long n_pixels, hipStream_t s);
+}
+
+namespace {
+void merr(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    pth_set_error(buf);
+}
+#define MHIP(x)                                                                                  \
+    do {                                                                                         \
+        hipError_t e_ = (x);                                                                     \
+        if (e_ != hipSuccess) { merr("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return -1; } \
+    } while (0)
+
+// ---- RCCL through dlopen (the few entry points of the single-process form) ----
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Reduce;
+    }
+};
+enum { kNcclFloat = 7, kNcclSum = 0 };
+}  // namespace
+
+struct pt_multi {
+    int w = 0, h = 0;
+    std::vector<int> dev;
+    std::vector<pt_ctx *> ctx;
+    std::vector<std::vector<int32_t>> rects;   // per context: its tiles as x0 y0 x1 y1
+    std::vector<int32_t> owner;                // per spiral tile
+    void *reduced = nullptr;                   // on dev[0]: the summed RGBA framebuffer
+    void *staging = nullptr;                   // on dev[0]: one peer's framebuffer at a time
+    hipStream_t stream = nullptr;              // on dev[0]
+    bool use_rccl = false;
+    Rccl rccl;
+    std::vector<void *> comms;
+    std::vector<hipStream_t> rstreams;         // one per device for the RCCL group
+    std::vector<float> host_tmp;
+};
+
+// longest-processing-time greedy (costliest tile first, ties by spiral index, to the least loaded owner, ties to the
+// lowest index): the map of pathtrace_amd/distributed.py balanced_owners, integer arithmetic only
+static std::vector<int32_t> balanced_owners(const std::vector<uint64_t> &cost, int n)
+{
+    std::vector<int> order(cost.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    std::vector<uint64_t> load(n, 0);
+    std::vector<int32_t> own(cost.size(), 0);
+    for (int k : order) {
+        int best = 0;
+        for (int r = 1; r < n; r++)
+            if (load[r] < load[best]) best = r;
+        own[k] = best;
+        load[best] += cost[k];
+    }
+    return own;
+}
+
+extern "C" void pt_multi_destroy(pt_multi *m)
+{
+    if (!m) return;
+    for (size_t i = 0; i < m->comms.size(); i++)
+        if (m->comms[i]) m->rccl.CommDestroy(m->comms[i]);
+    for (size_t i = 0; i < m->rstreams.size(); i++)
+        if (m->rstreams[i]) { (void)hipSetDevice(m->dev[i]); (void)hipStreamDestroy(m->rstreams[i]); }
+    for (pt_ctx *c : m->ctx) pt_destroy(c);
+    if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+    if (m->reduced) (void)hipFree(m->reduced);
+    if (m->staging) (void)hipFree(m->staging);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, int32_t n_devices, const int32_t *devices,
+                                     int32_t block_w, int32_t block_h)
+{
+    if (!scene || !config || n_devices < 1 || !devices || block_w < 1 || block_h < 1) { merr("pt_multi_create: bad argument"); return nullptr; }
+    pt_multi *m = new pt_multi();
+    auto fail = [&]() { std::string e = pt_last_error(); pt_multi_destroy(m); pth_set_error(e); return (pt_multi *)nullptr; };
+    m->w = config->width; m->h = config->height;
+    for (int i = 0; i < n_devices; i++) {
+        pt_config pc = *config;
+        pc.device = devices[i];
+        pt_ctx *c = pt_create(scene, &pc);
+        if (!c) return fail();
+        m->ctx.push_back(c);
+        m->dev.push_back(devices[i]);
+    }
+    // tiles in spiral order and their cost: World::hit queries of one sample per pixel plus one unit per camera sample,
+    // counted on the first device (deterministic: the RNG is keyed by pixel and sample)
+    const int n_tiles = pth_spiral_tiles(m->w, m->h, block_w, block_h, nullptr, 0);
+    std::vector<int32_t> tiles((size_t)n_tiles * 4);
+    pth_spiral_tiles(m->w, m->h, block_w, block_h, tiles.data(), n_tiles);
+    if (n_devices == 1 || getenv("PATHTRACE_HIP_ROUND_ROBIN")) {
+        m->owner.resize(n_tiles);
+        for (int k = 0; k < n_tiles; k++) m->owner[k] = k % n_devices;
+    } else {
+        std::vector<uint64_t> cost(n_tiles);
+        pt_counters prev{}, cur{};
+        if (pt_clear_framebuffer(m->ctx[0]) || pt_get_counters(m->ctx[0], &prev)) return fail();
+        for (int k = 0; k < n_tiles; k++) {
+            if (pt_render_tiles_async(m->ctx[0], 1, &tiles[4 * k], 0, 1) || pt_get_counters(m->ctx[0], &cur)) return fail();
+            cost[k] = (cur.rays - prev.rays) + (cur.camera_samples - prev.camera_samples);
+            prev = cur;
+        }
+        if (pt_clear_framebuffer(m->ctx[0])) return fail();
+        m->owner = balanced_owners(cost, n_devices);
+    }
+    m->rects.resize(n_devices);
+    for (int k = 0; k < n_tiles; k++)
+        m->rects[m->owner[k]].insert(m->rects[m->owner[k]].end(), tiles.begin() + 4 * k, tiles.begin() + 4 * k + 4);
+    const size_t bytes = (size_t)m->w * m->h * 16;
+    if (hipSetDevice(m->dev[0]) != hipSuccess || hipMalloc(&m->reduced, bytes) != hipSuccess || hipMalloc(&m->staging, bytes) != hipSuccess ||
+        hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) {
+        merr("pt_multi_create: allocating the reduce buffers on device %d failed", m->dev[0]);
+        return fail();
+    }
+    // peers: let the root read their memory directly where the topology allows it (hipMemcpyPeer works either way)
+    for (int i = 1; i < n_devices; i++)
+        if (m->dev[i] != m->dev[0]) { int can = 0; (void)hipDeviceCanAccessPeer(&can, m->dev[0], m->dev[i]); if (can) (void)hipDeviceEnablePeerAccess(m->dev[i], 0); }
+    (void)hipGetLastError();
+    if (getenv("PATHTRACE_HIP_MULTI_RCCL")) {
+        bool distinct = true;
+        for (int i = 0; i < n_devices; i++)
+            for (int j = 0; j < i; j++) distinct = distinct && m->dev[i] != m->dev[j];
+        if (!distinct) { merr("pt_multi_create: PATHTRACE_HIP_MULTI_RCCL needs distinct devices"); return fail(); }
+        if (!m->rccl.load()) { merr("pt_multi_create: librccl.so could not be loaded"); return fail(); }
+        m->comms.assign(n_devices, nullptr);
+        const int rc = m->rccl.CommInitAll(m->comms.data(), n_devices, m->dev.data());
+        if (rc != 0) { merr("pt_multi_create: ncclCommInitAll: %s", m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "error"); return fail(); }
+        m->rstreams.assign(n_devices, nullptr);
+        for (int i = 0; i < n_devices; i++)
+            if (hipSetDevice(m->dev[i]) != hipSuccess || hipStreamCreateWithFlags(&m->rstreams[i], hipStreamNonBlocking) != hipSuccess) {
+                merr("pt_multi_create: stream on device %d", m->dev[i]);
+                return fail();
+            }
+        m->use_rccl = true;
+    }
+    return m;
+}
+
+extern "C" int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp_end)
+{
+    if (!m) { merr("pt_multi_render_async: null"); return -1; }
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        const int n = (int)(m->rects[i].size() / 4);
+        if (n && pt_render_tiles_async(m->ctx[i], n, m->rects[i].data(), spp_begin, spp_end)) return -1;
+    }
+    return 0;
+}
+
+extern "C" int pt_multi_poll(pt_multi *m, uint64_t *samples_done, uint64_t *rays_done)
+{
+    if (!m) { merr("pt_multi_poll: null"); return -1; }
+    uint64_t s = 0, r = 0;
+    int done = 1;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        if (m->rects[i].empty()) continue;
+        uint64_t si = 0, ri = 0;
+        const int d = pt_poll(m->ctx[i], &si, &ri);
+        if (d < 0) return -1;
+        done = done && d;
+        s += si; r += ri;
+    }
+    if (samples_done) *samples_done = s;
+    if (rays_done) *rays_done = r;
+    return done;
+}
+
+extern "C" int pt_multi_wait(pt_multi *m)
+{
+    if (!m) { merr("pt_multi_wait: null"); return -1; }
+    for (pt_ctx *c : m->ctx)
+        if (pt_wait(c)) return -1;
+    return 0;
+}
+
+// sum of the per-device framebuffers into m->reduced on the first device; the per-device buffers stay as they are, so a
+// render can go on after a read
+static int reduce_now(pt_multi *m)
+{
+    if (pt_multi_wait(m)) return -1;
+    const size_t npix = (size_t)m->w * m->h, bytes = npix * 16;
+    if (m->use_rccl) {
+        if (m->rccl.GroupStart() != 0) { merr("ncclGroupStart failed"); return -1; }
+        for (size_t i = 0; i < m->ctx.size(); i++) {
+            const int rc = m->rccl.Reduce(pt_device_framebuffer(m->ctx[i]), i == 0 ? m->reduced : nullptr, npix * 4, kNcclFloat, kNcclSum, 0,
+                                          m->comms[i], m->rstreams[i]);
+            if (rc != 0) { merr("ncclReduce: %s", m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "error"); return -1; }
+        }
+        if (m->rccl.GroupEnd() != 0) { merr("ncclGroupEnd failed"); return -1; }
+        for (size_t i = 0; i < m->ctx.size(); i++) { MHIP(hipSetDevice(m->dev[i])); MHIP(hipStreamSynchronize(m->rstreams[i])); }
+        MHIP(hipSetDevice(m->dev[0]));
+        return 0;
+    }
+    MHIP(hipSetDevice(m->dev[0]));
+    MHIP(hipMemcpyAsync(m->reduced, pt_device_framebuffer(m->ctx[0]), bytes, hipMemcpyDeviceToDevice, m->stream));
+    for (size_t i = 1; i < m->ctx.size(); i++) {
+        if (m->rects[i].empty()) continue;
+        if (m->dev[i] == m->dev[0]) MHIP(hipMemcpyAsync(m->staging, pt_device_framebuffer(m->ctx[i]), bytes, hipMemcpyDeviceToDevice, m->stream));
+        else MHIP(hipMemcpyPeerAsync(m->staging, m->dev[0], pt_device_framebuffer(m->ctx[i]), m->dev[i], bytes, m->stream));
+        ptd::launch_add_fb(m->reduced, m->staging, (long long)npix, m->stream);
+        MHIP(hipGetLastError());
+    }
+    MHIP(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+extern "C" int pt_multi_read_framebuffer(pt_multi *m, float *rgb_sum)
+{
+    if (!m || !rgb_sum) { merr("pt_multi_read_framebuffer: null argument"); return -1; }
+    if (reduce_now(m)) return -1;
+    const size_t n = (size_t)m->w * m->h;
+    m->host_tmp.resize(n * 4);
+    MHIP(hipMemcpy(m->host_tmp.data(), m->reduced, n * 16, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) { rgb_sum[3 * i] = m->host_tmp[4 * i]; rgb_sum[3 * i + 1] = m->host_tmp[4 * i + 1]; rgb_sum[3 * i + 2] = m->host_tmp[4 * i + 2]; }
+    return 0;
+}
+
+extern "C" int pt_multi_snapshot_framebuffer(pt_multi *m, float *rgb_sum, uint64_t *samples_accumulated)
+{
+    if (!m || !rgb_sum) { merr("pt_multi_snapshot_framebuffer: null argument"); return -1; }
+    const size_t n = (size_t)m->w * m->h * 3;
+    std::fill(rgb_sum, rgb_sum + n, 0.0f);
+    std::vector<float> part(n);
+    uint64_t acc = 0;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        if (m->rects[i].empty()) continue;
+        uint64_t a = 0;
+        if (pt_snapshot_framebuffer(m->ctx[i], part.data(), &a)) return -1;
+        acc += a;
+        for (size_t k = 0; k < n; k++) rgb_sum[k] += part[k];   // disjoint tiles: one non-zero term per pixel
+    }
+    if (samples_accumulated) *samples_accumulated = acc;
+    return 0;
+}
+
+extern "C" int pt_multi_get_counters(pt_multi *m, pt_counters *out)
+{
+    if (!m || !out) { merr("pt_multi_get_counters: null argument"); return -1; }
+    pt_counters s{};
+    for (pt_ctx *c : m->ctx) {
+        pt_counters k{};
+        if (pt_get_counters(c, &k)) return -1;
+        uint64_t *d = (uint64_t *)&s;
+        const uint64_t *q = (const uint64_t *)&k;
+        for (size_t j = 0; j < sizeof(pt_counters) / 8; j++) d[j] += q[j];
+    }
+    *out = s;
+    return 0;
+}
+
+extern "C" int pt_multi_clear(pt_multi *m)
+{
+    if (!m) { merr("pt_multi_clear: null"); return -1; }
+    for (pt_ctx *c : m->ctx)
+        if (pt_clear_framebuffer(c)) return -1;
+    return 0;
+}
+
+extern "C" int pt_multi_device_count(pt_multi *m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" int pt_multi_tile_owners(pt_multi *m, int32_t *owners, int32_t max_tiles)
+{
+    if (!m) return 0;
+    const int n = (int)m->owner.size();
+    if (owners)
+        for (int k = 0; k < n && k < max_tiles; k++) owners[k] = m->owner[k];
+    return n;
+}

@@ -964,7 +964,11 @@ public:
     pth_config config{};
 };
 
-// render_type "hip_wavefront": start_render enqueues the whole image on the GPU and returns; sync_progress polls.
+// render_type "hip_wavefront": start_render enqueues the whole image on the GPU(s) and returns; sync_progress polls.
+// Every visible device takes part (pt_multi: tiles of block_width x block_height in NaiveSpiral order, cost-balanced
+// ownership, one sum into the first device at the end) -- the counterpart of Tiled's config.threads workers over one tile
+// queue (renderer.h:553-603).  PATHTRACE_HIP_DEVICES="0,1,.." picks the devices; an ordinal may repeat ("0,0": two
+// contexts on one GPU, the rehearsal of the multi-GPU path on a one-GPU box).  One device: a single context, no tiles.
 class HipWavefront : public Renderer {
 public:
     HipWavefront(const pth_config &cfg, const pt_scene_desc *scene)
@@ -974,22 +978,41 @@ public:
         pc.width = cfg.width; pc.height = cfg.height; pc.max_bounces = cfg.max_bounces; pc.light_samples = cfg.light_samples;
         pc.russian_roulette = cfg.russian_roulette; pc.only_direct_illumination = cfg.only_direct_illumination;
         pc.normal_offset = cfg.normal_offset; pc.seed = 0; pc.device = -1; pc.max_paths_in_flight = 0;
-        ctx = pt_create(scene, &pc);
-        if (!ctx) throw JsonError(std::string("pt_create: ") + pt_last_error());
+        std::vector<int32_t> devices;
+        if (const char *e = getenv("PATHTRACE_HIP_DEVICES")) {
+            for (const char *p = e; *p;) {
+                char *end = nullptr;
+                long v = strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int32_t)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        } else {
+            for (int d = 0; d < pt_device_count(); d++) devices.push_back(d);
+        }
+        if (devices.size() > 1) {
+            multi = pt_multi_create(scene, &pc, (int32_t)devices.size(), devices.data(), std::max(cfg.block_width, 1), std::max(cfg.block_height, 1));
+            if (!multi) throw JsonError(std::string("pt_multi_create: ") + pt_last_error());
+        } else {
+            if (devices.size() == 1) pc.device = devices[0];
+            ctx = pt_create(scene, &pc);
+            if (!ctx) throw JsonError(std::string("pt_create: ") + pt_last_error());
+        }
         framebuffer.assign((size_t)cfg.width * cfg.height * 3, 0.0f);
     }
-    ~HipWavefront() override { pt_destroy(ctx); }
+    ~HipWavefront() override { pt_destroy(ctx); pt_multi_destroy(multi); }
     void preprocess() override {}
     void start_render(std::chrono::high_resolution_clock::time_point program_start) override
     {
         render_start = std::chrono::high_resolution_clock::now();
         (void)program_start;
-        if (pt_render_async(ctx, 0, 0, config.width, config.height, 0, config.samples)) throw JsonError(pt_last_error());
+        const int rc = multi ? pt_multi_render_async(multi, 0, config.samples) : pt_render_async(ctx, 0, 0, config.width, config.height, 0, config.samples);
+        if (rc) throw JsonError(pt_last_error());
     }
     void sync_progress() override
     {
         uint64_t samples = 0, rays = 0;
-        int r = pt_poll(ctx, &samples, &rays);
+        int r = multi ? pt_multi_poll(multi, &samples, &rays) : pt_poll(ctx, &samples, &rays);
         if (r < 0) throw JsonError(pt_last_error());
         long total = (long)config.samples * config.width * config.height;
         double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - render_start).count();
@@ -999,7 +1022,8 @@ public:
         // main loop (one sync_progress per 0.5 s, main.cpp:158-163) at most two previews per second
         if (r == 0 && dt - last_preview >= 0.5) {
             uint64_t acc = 0;
-            if (pt_snapshot_framebuffer(ctx, framebuffer.data(), &acc)) throw JsonError(pt_last_error());
+            if (multi ? pt_multi_snapshot_framebuffer(multi, framebuffer.data(), &acc) : pt_snapshot_framebuffer(ctx, framebuffer.data(), &acc))
+                throw JsonError(pt_last_error());
             const long npix = (long)config.width * config.height;
             if (pth_write_ppm(config.ppm_output_path, framebuffer.data(), config.width, config.height, (int32_t)(1 + (long)acc / npix), config.exposure))
                 throw JsonError(pt_last_error());
@@ -1011,18 +1035,20 @@ public:
     bool is_done() override { return completed; }
     void finalize() override
     {
-        if (pt_wait(ctx)) throw JsonError(pt_last_error());
+        if (multi ? pt_multi_wait(multi) : pt_wait(ctx)) throw JsonError(pt_last_error());
         double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - render_start).count();
         pt_counters c{};
-        pt_get_counters(ctx, &c);
-        if (pt_read_framebuffer(ctx, framebuffer.data())) throw JsonError(pt_last_error());
+        if (multi ? pt_multi_get_counters(multi, &c) : pt_get_counters(ctx, &c)) throw JsonError(pt_last_error());
+        if (multi ? pt_multi_read_framebuffer(multi, framebuffer.data()) : pt_read_framebuffer(ctx, framebuffer.data())) throw JsonError(pt_last_error());
         printf("\ntime taken to compute %g\n", dt);
+        if (multi) printf("rendered on %d devices\n", pt_multi_device_count(multi));
         printf("computed %llu camera rays in %gs, at %g rays per second\n", (unsigned long long)c.camera_samples, dt, c.camera_samples / dt);
         printf("computed %llu rays, at %g rays per second\n", (unsigned long long)c.rays, c.rays / dt);
         if (pth_write_ppm(config.ppm_output_path, framebuffer.data(), config.width, config.height, config.samples, config.exposure))
             throw JsonError(pt_last_error());
     }
     pt_ctx *ctx = nullptr;
+    pt_multi *multi = nullptr;
     std::chrono::high_resolution_clock::time_point render_start;
     double last_preview = 0.0;
     int previews = 0;

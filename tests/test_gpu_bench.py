@@ -1,0 +1,66 @@
+"""bench.py as the driver runs it (a plain command): N = 1, and N = 2 started by bench.py itself.
+On a one-GPU box the two ranks share GPU 0 (PT_BENCH_REHEARSAL=1: gloo instead of RCCL, the reduce staged through host
+memory); the image must be the N = 1 image bit for bit, which the framebuffer checksum and the ray counters show.
+Plus one RCCL ("nccl") process group of world size 1 on the GPU: init, the framebuffer reduce of the path, destroy."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(args, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_and_matches_one_rank():
+    common = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-configs"]
+    small = {"PT_BENCH_SIZE": "640x360"}
+    one = run_bench(["--gpus", "1"] + common, small)
+    two = run_bench(["--gpus", "2"] + common, dict(small, PT_BENCH_REHEARSAL="1"))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    for k in ("spp_total", "camera_samples", "rays", "framebuffer_sum"):
+        assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
+    for d in (one, two):
+        assert d["roofline"]["bound"] in ("hbm", "valu") and d["value"] > 0 and d["steps"] == 4
+
+
+def test_rccl_world_size_one_reduce_of_the_library_framebuffer():
+    code = r"""
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import pathtrace_amd as pt
+from pathtrace_amd.distributed import reduce_framebuffer
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+sc = pt.Scene(os.path.join(%r, "scenes", "cornell_box.json"), 128, 72)
+r = pt.Renderer(sc, device=0)
+fb = torch.zeros((72, 128, 4), dtype=torch.float32, device="cuda:0")
+r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
+r.render_async(0, 4); r.wait()
+before = fb.clone()
+dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)          # RCCL kernel on the library-rendered tensor
+dist.all_reduce(fb, op=dist.ReduceOp.SUM)              # world size 1: identity
+torch.cuda.synchronize()
+assert torch.equal(fb, before) and float(fb.sum()) > 0
+r.set_device_framebuffer(None, 0)
+ref = pt.Renderer(sc, device=0).render(4)
+assert np.array_equal(before.cpu().numpy()[..., :3], ref)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+""" % (ROOT, ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1000:], p.stderr[-2000:])

@@ -56,3 +56,52 @@ def test_full_frame_windows_counters_and_tile_partition(oracle, scene, w, h):
         assert n_tiles == -(-w // 128) * -(-h // 128)
         assert np.array_equal(bits(r.framebuffer()), bits(whole)) and r.counters() == c
     r.close()
+
+
+# BASELINE.json configs 3, 4 and the frame of config 5 at their FULL sample counts on one GPU.
+FULL = [("cornell_box_small_lights", 1920, 1080, 4096, 16, 8.05), ("cornell_box_with_volume", 1920, 1080, 2048, 16, 8.72),
+        ("cornell_box", 3840, 2160, 8192, 4, 8.31)]
+
+
+@pytest.mark.parametrize("scene,w,h,spp,batch,rays_per_sample", FULL)
+def test_full_sample_count_of_baseline_configs(oracle, scene, w, h, spp, batch, rays_per_sample):
+    """The whole configuration (every sample of every pixel) through the wavefront path, 33 M paths per batch: counter
+    conservation at 10^10..10^11 camera samples, the survey's ray mix, and -- at full spp -- the framebuffer SUM of an
+    8x8 window equal to the oracle's bit for bit (the oracle renders the same (pixel, sample) streams in sample order).
+    High sample indices are also checked batch-wise: samples [spp - 16, spp) of four windows, GPU vs oracle."""
+    L = 4
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, max_paths_in_flight=w * h * batch)
+    for s in range(0, spp, batch):
+        r.render_async(s, s + batch)
+    fb = r.framebuffer()
+    c = r.counters()
+    assert c["camera_samples"] == w * h * spp
+    assert c["rays"] == c["extension_rays"] + c["shadow_rays"] and c["shadow_rays"] == L * c["extension_hits"]
+    assert c["term_miss"] + c["term_rr"] + c["term_emitter"] + c["term_pdf"] + c["term_bounce_limit"] == c["camera_samples"]
+    assert c["extension_rays"] - c["extension_hits"] == c["term_miss"]
+    assert abs(c["rays"] / c["camera_samples"] - rays_per_sample) < 0.02 * rays_per_sample   # SURVEY.md 6: 16:9 ray mixes
+    assert not np.isnan(fb).any() and (fb >= 0).all()
+    osc = oracle.Scene.from_json(scene_path(scene))
+    cfg = oracle.make_config(w, h, spp)
+    # full-spp window in the lit interior of the frame
+    x0, y0 = w // 2 - 4, h // 3
+    ofb = np.zeros((h, w, 3), np.float32)
+    osc.render_stream(cfg, seed=0, rect=(x0, y0, x0 + 8, y0 + 8), threads=8, fb=ofb)
+    g, o = fb[y0:y0 + 8, x0:x0 + 8], ofb[y0:y0 + 8, x0:x0 + 8]
+    assert ((bits(g) == bits(o)) | (g == o)).all(), (scene, "full-spp window")
+    assert (o > 0).any()
+    # the last batch of samples on four windows
+    r.clear()
+    rng = np.random.default_rng(spp)
+    for _ in range(4):
+        wx, wy = int(rng.integers(0, w - 16)), int(rng.integers(0, h - 16))
+        rect = (wx, wy, wx + 16, wy + 16)
+        r.clear()
+        r.render_async(spp - 16, spp, rect)
+        gw = r.framebuffer()[wy:wy + 16, wx:wx + 16]
+        ofb = np.zeros((h, w, 3), np.float32)
+        osc.render_stream(cfg, seed=0, rect=rect, s0=spp - 16, s1=spp, threads=4, fb=ofb)
+        ow = ofb[wy:wy + 16, wx:wx + 16]
+        assert ((bits(gw) == bits(ow)) | (gw == ow)).all(), (scene, rect)
+    r.close()

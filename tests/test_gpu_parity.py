@@ -295,6 +295,8 @@ def test_async_protocol_and_errors():
     with pytest.raises(pt.PathtraceError, match="u, v of a rect"):
         pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))
     s = json.load(open(scene_path("cornell_box_with_volume")))
-    s["primitives"][2]["primitive"] = "white_wall"          # a volume whose boundary is a rect: not implemented on device
+    # a medium whose boundary is another medium is refused (box, sphere and rect boundaries render: test_gpu_fuzz.py)
+    s["primitives"].append({"id": "fog2", "type": "volume", "primitive": "fog", "density": 0.01, "color": [0.5, 0.5, 0.5]})
+    s["instances"].append({"type": "ref", "primitive": {"id": "fog2"}})
     with pytest.raises(pt.PathtraceError):
         pt.Renderer(pt.Scene(text=json.dumps(s), width=64, height=64))
