@@ -79,7 +79,7 @@ def file_derived_profile(dom):
     (tools/profile_gpu.sh writes them; they are NOT measured by this run and are labelled with their file)."""
     import glob
     out = {"traffic": None, "traffic_source": None, "valu": None}
-    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), key=os.path.getmtime)
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # rNNx tags sort by round
     if tfiles:
         try:
             d = json.load(open(tfiles[-1]))
@@ -87,7 +87,7 @@ def file_derived_profile(dom):
             out["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
         except Exception:
             pass
-    mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_instruction_mix.json")), key=os.path.getmtime)
+    mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instruction_mix.json")))
     if mixes:
         try:
             mk = json.load(open(mixes[-1])).get(dom)
