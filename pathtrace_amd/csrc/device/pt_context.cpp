@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -460,11 +461,40 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
     // needs neither them nor the pushes), ENTER's skip target re-indexed; stored behind the general program
     const int n_general = (int)ops.size() - 1;
+    // flat mode (pt_device.h DScene::chains): few instances, shallow tree -> leaves only, ancestors checked afterwards
+    const bool flat = sc->n_instances <= PT_FLAT_MAX_INSTANCES && max_depth <= PT_MAX_STACK && !getenv("PATHTRACE_HIP_NO_FLAT");
+    // (the root's ENTER stays: a wave of camera rays that miss the scene's box leaves the program after one op)
+    auto in_fast = [&](const DOp &o) { return o.kind != OP_COMBINE && !(flat && o.kind == OP_ENTER && &o != &ops[0]); };
     std::vector<int> fast_index(n_general + 1, 0);
-    for (int i = 0, k = 0; i <= n_general; i++) { fast_index[i] = k; if (i < n_general && ops[i].kind != OP_COMBINE) k++; }
+    for (int i = 0, k = 0; i <= n_general; i++) { fast_index[i] = k; if (i < n_general && in_fast(ops[i])) k++; }
     const int n_fast = fast_index[n_general];
+    std::vector<float4> chains;
+    int n_chain = 0;
+    if (flat) {
+        // One box per leaf suffices: its PARENT's.  A node's box is surrounding_box of its children's (aabb.h:55-64:
+        // componentwise fmin / fmax), so every ancestor's box contains the parent's bound for bound, and the slab test is
+        // monotone in the bounds -- (b - o) * invD and the min / max over them only move outwards when a bound does,
+        // rounding included -- hence a ray that hits the parent's box hits every ancestor's.  Leaves hanging off the root
+        // get an all-space box (the root's ENTER op is in the program).
+        n_chain = 1;
+        chains.assign((size_t)sc->n_instances * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (size_t k = 0; k < chains.size(); k += 2) {
+            chains[k] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+            chains[k + 1] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+        }
+        std::vector<int> open_nodes;   // ENTER ops whose subtree holds the current op
+        for (int i = 0; i < n_general; i++) {
+            while (!open_nodes.empty() && ops[open_nodes.back()].a <= i) open_nodes.pop_back();
+            if (ops[i].kind == OP_ENTER) open_nodes.push_back(i);
+            else if (ops[i].kind >= OP_LEAF_RECT_XY && open_nodes.size() > 1) {
+                const float *bb = ops[open_nodes.back()].f;
+                chains[(size_t)ops[i].a * 2] = make_float4(bb[0], bb[1], bb[2], 0.f);
+                chains[(size_t)ops[i].a * 2 + 1] = make_float4(bb[3], bb[4], bb[5], 0.f);
+            }
+        }
+    } else chains.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
     for (int i = 0; i < n_general; i++) {
-        if (ops[i].kind == OP_COMBINE) continue;
+        if (!in_fast(ops[i])) continue;
         DOp f = ops[i];
         {   // the fast sweep compares positions as floats: its own index rides in push_slot (unused there), ENTER's target in f[6]
             const float self = (float)fast_index[i];
@@ -537,6 +567,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         return -1;
     S.n_insts = (int)insts.size(); S.n_prims = (int)prims.size(); S.n_mats = (int)mats.size();
     S.n_ops = n_general; S.ops_fast_off = n_general + 1; S.n_ops_fast = n_fast;
+    S.n_chain = n_chain;
+    if (dev_upload(c, &S.chains, chains)) return -1;
     S.n_lights = (int)lights.size(); S.n_vol = nvol;
     S.stack_depth = std::max(max_depth, 1);
     const pt_camera &cm = sc->camera;

@@ -91,6 +91,7 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
     // second half: primitive parameters, needed only after the ray has been transformed
     float g[16];         // g[i] = "f[12 + i]" of the table above
 };
+#define PT_FLAT_MAX_INSTANCES 24
 #define PT_MAX_STACK 8   // short-stack slots per lane and ray held in LDS (tree height <= 8)
 
 struct DCamera {
@@ -118,6 +119,13 @@ struct DScene {
     int32_t n_insts, n_prims, n_mats, n_ops, n_lights, n_vol;
     int32_t stack_depth;         // short-stack slots the program uses
     int32_t ops_fast_off, n_ops_fast;   // the fast program (no COMBINE ops) sits at ops + ops_fast_off
+    // Small scenes (PT_FLAT_MAX_INSTANCES): the fast program keeps only the ROOT's ENTER op -- every leaf is tested, which
+    // is what the node boxes of a handful of room-sized instances amount to anyway -- and the winner's PARENT box (it
+    // implies every ancestor's, pt_context.cpp) is tested afterwards, per lane, from this table: chains[instance][2] =
+    // (min xyz, max xyz), an all-space box for children of the root.  n_chain = 0: the fast program carries all its ENTER
+    // ops (pt_kernels.hip world_hit_fast).
+    const float4 *chains;
+    int32_t n_chain, pad_chain;
     int32_t tame;                // every matrix entry / bound of the program's leaves is zero or within [2^-20, 2^20]: the
                                  // sweep may use the unscaled exact division of pt_fdiv.h (pt_kernels.hip world_hit)
     DCamera cam;

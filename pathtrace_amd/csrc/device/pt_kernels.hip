@@ -762,6 +762,24 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
 #undef FOLD
 #undef OPF
     }
+    if (S.n_chain) {
+        // flat program (pt_device.h DScene::chains): below the root no node box was tested on the way.  bvh_node::hit would
+        // have dropped a leaf whose ancestor box the ray misses; the closest leaf over ALL leaves is the tree's answer iff
+        // its own ancestors are hit (it is then also the closest of the leaves the tree reaches, ties by order included),
+        // and its parent's box stands for all of them.  So only that one box is tested -- per lane, the slab arithmetic of
+        // the ENTER ops -- and a lane whose winner fails it sends the wave to the general sweep.
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const float4 *ch = S.chains + (size_t)max(cur_id[r] >> 3, 0) * 2;
+            const float4 lo = ch[0], hi = ch[1];
+            const float ax = (lo.x - A.x) * inv[r].x, cx = (hi.x - A.x) * inv[r].x;
+            const float ay = (lo.y - A.y) * inv[r].y, cy = (hi.y - A.y) * inv[r].y;
+            const float az = (lo.z - A.z) * inv[r].z, cz = (hi.z - A.z) * inv[r].z;
+            const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
+            const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
+            chk = ((tmax <= tmin) && cur_id[r] >= 0) ? NAN : chk;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = (cur_id[r] >= 0) ? cur_t[r] : 0.0f; out_id[r] = cur_id[r]; }
     return is_nanf(chk);
