@@ -10,13 +10,14 @@ torch.distributed.run by someone else it runs as one rank (RANK / LOCAL_RANK / W
 
 Workload (BASELINE.json configs[1]): scenes/cornell_box.json, 1920x1080, max_bounces 10, light_samples 4, russian
 roulette on, normal_offset 1e-4.  One *step* = one pass of the hot path over the whole frame at 16 samples per pixel
-(33 M camera samples); the default K = 64 steps is exactly the 1024 spp of configs[1].  "ray" = one World::hit query,
+(33 M camera samples); the default K = 64 steps is exactly the 1024 spp of configs[1].  Steps are enqueued two per
+wavefront launch (66 M paths per batch).  "ray" = one World::hit query,
 extension + shadow, the reference's own unit (integrator.h:192,247).
 
 N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
 partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over measured per-tile ray counts
 (pathtrace_amd/distributed.py; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank k mod N).  Every rank renders ITS tiles for all
-K steps with no communication -- N steps per launch, so that a wavefront batch stays at ~33 M paths -- and ONE RCCL
+K steps with no communication -- 2 N steps per launch, so that a wavefront batch stays at ~66 M paths -- and ONE RCCL
 sum-reduce of the framebuffer to rank 0 ends the timed region.  PT_BENCH_SCALING=weak keeps per-GPU work fixed instead
 (every step renders 16*N spp).
 
@@ -185,11 +186,12 @@ def main():
             planner.close()
         my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
     setup_ms = (time.perf_counter() - setup_t0) * 1e3
-    # One launch = `group` steps of this rank's pixels: a wavefront batch of ~W*H*16 = 33 M paths at every N.
+    # One launch = `group` steps of this rank's pixels: a wavefront batch of ~W*H*32 = 66 M paths at every N (measured at
+    # N = 1: 33 M-path batches 28.9, 66 M 29.8, 133 M 30.0 Grays/s -- the thin late bounces of a batch cost less per path).
     #   strong (default): total work fixed -- K steps of 16 spp over the frame; each rank renders its 1/N of the pixels
-    #                     for all K steps, N steps per launch
+    #                     for all K steps, 2 N steps per launch
     #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
-    group = n
+    group = 2 * n
     spp_launch = SPP_PER_STEP * group
     total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)

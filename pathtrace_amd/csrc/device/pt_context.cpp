@@ -612,10 +612,11 @@ static int alloc_streams(pt_ctx *c)
     if (dev_alloc(c, &ctr, PT_COUNTER_BANKS)) return -1;
     HIP_TRY(hipMemset(c->fb_own, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
     HIP_TRY(hipMemset(ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS));
-    // every lane owns a full set of stream buffers (P slots, 288 B each at light_samples = 4); 2 lanes measured best
-    // (1: the thin late bounces are exposed, 3: +2 %, 4: no further gain)
+    // every lane owns a full set of stream buffers (P slots, 288 B each at light_samples = 4).  Measured on cornell_box
+    // 1080p (round 2): 1 lane 23.9, 2 lanes 28.9, 3 lanes 29.3, 4 lanes 27.9 Grays/s -- one lane leaves the thin late
+    // bounces exposed, with three the chip always has a wide kernel to run
     const char *env = getenv("PATHTRACE_HIP_LANES");
-    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 2;
+    c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 3;
     c->n_lanes_alloc = c->n_lanes;
     for (int l = 0; l < c->n_lanes; l++) {
         Lane &ln = c->lanes[l];
