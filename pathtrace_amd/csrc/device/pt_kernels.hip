@@ -33,6 +33,12 @@
 namespace ptd {
 
 #define PT_BLOCK 256
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 6     // waves per SIMD k_shade is compiled for (80 VGPRs)
+#endif
+#ifndef PT_CONNECT_WAVES
+#define PT_CONNECT_WAVES 6   // k_connect with two rays per sweep
+#endif
 #define PT_PI_D 3.14159265358979323846
 #define PT_PI_F 3.14159274f
 
@@ -1300,7 +1306,7 @@ DEVI float material_value_of(int type, float cosine)
 // scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
 // of the others.
 template <bool TEX, int LM>
-__global__ __launch_bounds__(PT_BLOCK, 6) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
@@ -1659,7 +1665,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
 template <int NR, bool TEX, bool GA>
-__global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : 6) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : PT_CONNECT_WAVES) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream

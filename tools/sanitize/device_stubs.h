@@ -1,0 +1,21 @@
+// The device entry points the host front end (pt_host.cpp) refers to, stubbed for the CPU-only sanitizer builds.
+#pragma once
+#include "pathtrace_hip.h"
+extern "C" pt_ctx *pt_create(const pt_scene_desc *, const pt_config *) { return nullptr; }
+extern "C" void pt_destroy(pt_ctx *) {}
+extern "C" int pt_render_async(pt_ctx *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) { return -1; }
+extern "C" int pt_poll(pt_ctx *, uint64_t *, uint64_t *) { return -1; }
+extern "C" int pt_wait(pt_ctx *) { return -1; }
+extern "C" int pt_read_framebuffer(pt_ctx *, float *) { return -1; }
+extern "C" int pt_snapshot_framebuffer(pt_ctx *, float *, uint64_t *) { return -1; }
+extern "C" int pt_get_counters(pt_ctx *, pt_counters *) { return -1; }
+extern "C" int pt_device_count(void) { return 0; }
+extern "C" pt_multi *pt_multi_create(const pt_scene_desc *, const pt_config *, int32_t, const int32_t *, int32_t, int32_t) { return nullptr; }
+extern "C" void pt_multi_destroy(pt_multi *) {}
+extern "C" int pt_multi_render_async(pt_multi *, int32_t, int32_t) { return -1; }
+extern "C" int pt_multi_poll(pt_multi *, uint64_t *, uint64_t *) { return -1; }
+extern "C" int pt_multi_wait(pt_multi *) { return -1; }
+extern "C" int pt_multi_read_framebuffer(pt_multi *, float *) { return -1; }
+extern "C" int pt_multi_snapshot_framebuffer(pt_multi *, float *, uint64_t *) { return -1; }
+extern "C" int pt_multi_get_counters(pt_multi *, pt_counters *) { return -1; }
+extern "C" int pt_multi_device_count(pt_multi *) { return 0; }

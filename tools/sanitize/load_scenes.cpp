@@ -5,14 +5,7 @@
 static std::string g_err;
 void pth_set_error(const std::string &m) { g_err = m; }
 extern "C" const char *pt_last_error(void) { return g_err.c_str(); }
-extern "C" pt_ctx *pt_create(const pt_scene_desc *, const pt_config *) { g_err = "stub"; return nullptr; }
-extern "C" void pt_destroy(pt_ctx *) {}
-extern "C" int pt_render_async(pt_ctx *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) { return -1; }
-extern "C" int pt_poll(pt_ctx *, uint64_t *, uint64_t *) { return -1; }
-extern "C" int pt_wait(pt_ctx *) { return -1; }
-extern "C" int pt_read_framebuffer(pt_ctx *, float *) { return -1; }
-extern "C" int pt_snapshot_framebuffer(pt_ctx *, float *, uint64_t *) { return -1; }
-extern "C" int pt_get_counters(pt_ctx *, pt_counters *) { return -1; }
+#include "device_stubs.h"
 int main(int argc, char **argv)
 {
     int bad = 0;

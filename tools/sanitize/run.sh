@@ -8,7 +8,7 @@
 set -e
 R=$(pwd)
 W=$(mktemp -d)
-FLAGS="-std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I$R/include"
+FLAGS="-std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -I$R/include -I$R/tools/sanitize"
 g++ $FLAGS tools/sanitize/load_scenes.cpp pathtrace_amd/csrc/host/pt_host.cpp -o $W/load_scenes
 g++ $FLAGS tools/sanitize/png_fuzz.cpp pathtrace_amd/csrc/host/pt_host.cpp -o $W/png_fuzz
 python3 - "$W" <<'PY'
