@@ -39,6 +39,9 @@ namespace ptd {
 #ifndef PT_CONNECT_WAVES
 #define PT_CONNECT_WAVES 6   // k_connect with two rays per sweep
 #endif
+#ifndef PT_CONNECT_WAVES_GA
+#define PT_CONNECT_WAVES_GA 5   // the same with sphere / constant_medium leaves (96 VGPRs: at 80 it spills 19; with_volume 24.6 -> 26.0 Grays/s)
+#endif
 #define PT_PI_D 3.14159265358979323846
 #define PT_PI_F 3.14159274f
 
@@ -1543,6 +1546,35 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                 sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
             };
+            // A rect light under a pure translation (tl = the inverse's translation), sampled from a finite point: the pdf's
+            // ray (ol, ldir) is the one rect::random just built, so rect::pdf_value (primitive.h:151-166) simplifies WITHOUT
+            // changing a bit:
+            //  * its t = (y - o.y) / d.y divides a float by itself -- d.y = y - o.y is the same subtraction -- which is
+            //    exactly 1 for a finite non-zero value and NaN otherwise (0 / 0);
+            //  * dot(v, normal) has two exact-zero terms: |dot| = |v.y| for the finite v here.
+            // The rect's fields may be per-lane values (the light a lane drew) or wave-uniform; `plane` is wave-uniform.
+            auto rect_light_sample = [&](const uint32_t k, const uint32_t kb, v3 tl, float x0, float z0, float x1, float z1, float y, int plane) {
+                const v3 ol = V(tl.x + hp.x, tl.y + hp.y, tl.z + hp.z);
+                const v3 os = shuffle(ol, plane);
+                const float area = (x1 - x0) * (z1 - z0);
+                const double rz = rnd(k0, k1, kb + 1);   // rect::random primitive.h:168-175 (first draw -> z, second -> x)
+                const double rx = rnd(k0, k1, kb + 2);
+                const float pz = (float)((double)z0 + rz * (double)(z1 - z0));
+                const float px = (float)((double)x0 + rx * (double)(x1 - x0));
+                const v3 ldir = vsub(shuffle(V(px, y, pz), plane), ol);
+                const float vl = vlen(ldir);
+                const float cos_l = vdot(vdivf(ldir, vl), hnu);
+                const v3 ds = shuffle(ldir, plane);
+                const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
+                const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
+                float light_pdf_l = 0.0f;
+                if (!(xh < x0 || xh > x1 || zh < z0 || zh > z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
+                    const float d2 = (tq * vl) * (tq * vl);
+                    const float cosine = fabsf(ds.y) / vl;
+                    light_pdf_l = d2 / (cosine * area);
+                }
+                emit_sample(k, ldir, cos_l, light_pdf_l);
+            };
             // one light (the common case): its index is wave-uniform, so its instance/primitive records are scalar
             // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
             // tr: the light's transform is a pure translation and every hit point of this wave is finite (same exactness
@@ -1560,35 +1592,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const DPrim &lpr = S.prims[lin.prim];
                 const bool tr = lin.ident && wave_finite;
                 if (tr && lpr.type == 0) {
-                    // A rect light under a pure translation, sampled from a finite point: the pdf's ray (ol, ldir) is the one
-                    // rect::random just built, so rect::pdf_value (primitive.h:151-166) simplifies WITHOUT changing a bit:
-                    //  * its t = (y - o.y) / d.y divides a float by itself -- d.y = y - o.y is the same subtraction -- which
-                    //    is exactly 1 for a finite non-zero value and NaN otherwise (0 / 0);
-                    //  * dot(v, normal) has two exact-zero terms: |dot| = |v.y| for the finite v here.
                     const DRect &lq = lpr.r[0];
-                    const v3 ol = V(lin.inv[3] + hp.x, lin.inv[7] + hp.y, lin.inv[11] + hp.z);
-                    const v3 os = shuffle(ol, lq.plane);
-                    const float area = (lq.x1 - lq.x0) * (lq.z1 - lq.z0);
-                    for (uint32_t k = 0; k < L; k++) {
-                        const uint32_t kb = base + NV + k * (3u + NV);
-                        const double rz = rnd(k0, k1, kb + 1);   // rect::random primitive.h:168-175 (first draw -> z, second -> x)
-                        const double rx = rnd(k0, k1, kb + 2);
-                        const float pz = (float)((double)lq.z0 + rz * (double)(lq.z1 - lq.z0));
-                        const float px = (float)((double)lq.x0 + rx * (double)(lq.x1 - lq.x0));
-                        const v3 ldir = vsub(shuffle(V(px, lq.y, pz), lq.plane), ol);
-                        const float vl = vlen(ldir);
-                        const float cos_l = vdot(vdivf(ldir, vl), hnu);
-                        const v3 ds = shuffle(ldir, lq.plane);
-                        const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
-                        const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
-                        float light_pdf_l = 0.0f;
-                        if (!(xh < lq.x0 || xh > lq.x1 || zh < lq.z0 || zh > lq.z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
-                            const float d2 = (tq * vl) * (tq * vl);
-                            const float cosine = fabsf(ds.y) / vl;
-                            light_pdf_l = d2 / (cosine * area);
-                        }
-                        emit_sample(k, ldir, cos_l, light_pdf_l);
-                    }
+                    for (uint32_t k = 0; k < L; k++)
+                        rect_light_sample(k, base + NV + k * (3u + NV), V(lin.inv[3], lin.inv[7], lin.inv[11]), lq.x0, lq.z0, lq.x1, lq.z1, lq.y, lq.plane);
                 } else {
                     for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, lpr, tr);
                 }
@@ -1597,9 +1603,19 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 // one it drew -- a few dozen v_cndmask instead of per-lane table gathers
                 const DInst &ia = S.insts[S.lights[0]], &ib = S.insts[S.lights[1]];
                 const DPrim &pa = S.prims[ia.prim], &pb = S.prims[ib.prim];
+                // both rects of one alignment under pure translations (cornell_box_small_lights): the shortcut above with the
+                // drawn light's eight fields selected per lane
+                const bool both_tr = ia.ident && ib.ident && wave_finite && pa.type == 0 && pb.type == 0 && pa.r[0].plane == pb.r[0].plane;
                 for (uint32_t k = 0; k < L; k++) {
                     const uint32_t kb = base + NV + k * (3u + NV);
                     const bool second = (int)(rnd(k0, k1, kb + 0) * 2.0) != 0;            // world.h:31-35
+                    if (both_tr) {
+                        const DRect &qa = pa.r[0], &qb = pb.r[0];
+                        rect_light_sample(k, kb, V(second ? ib.inv[3] : ia.inv[3], second ? ib.inv[7] : ia.inv[7], second ? ib.inv[11] : ia.inv[11]),
+                                          second ? qb.x0 : qa.x0, second ? qb.z0 : qa.z0, second ? qb.x1 : qa.x1, second ? qb.z1 : qa.z1,
+                                          second ? qb.y : qa.y, qa.plane);
+                        continue;
+                    }
                     DInst lin;
                     DPrim lpr;
 #pragma unroll
@@ -1665,7 +1681,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
 template <int NR, bool TEX, bool GA>
-__global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : PT_CONNECT_WAVES) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA : PT_CONNECT_WAVES)) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
