@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""One-off large fuzz of the device path against the oracle (not part of the test suite: minutes on the GPU box).
+
+    python tools/fuzz_gpu.py [first_seed] [n_seeds] > gpurun_out/fuzz.json
+
+For every seed: a generated scene (tests/scene_gen.py; varying instance counts so that both the flat program and the tree
+program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_NO_FASTDIV=1 on every 5th seed), rendered at
+96x64x4 on the GPU and by the oracle in stream mode; framebuffer bits and all nine path counters must agree."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+import pathtrace_amd as pt
+from oracle import pt_oracle as oracle
+from scene_gen import random_scene
+
+CTR = {"rays": "rays", "extension_rays": "ext_rays", "extension_hits": "ext_hits", "shadow_rays": "shadow_rays",
+       "term_miss": "term_miss", "term_rr": "term_rr", "term_emitter": "term_emitter", "term_pdf": "term_pdf",
+       "term_bounce_limit": "term_bounce_limit"}
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    oracle.build()
+    bad, rays, modes = [], 0, {"flat": 0, "tree": 0, "general": 0}
+    for seed in range(first, first + n):
+        n_inst = [None, 6, 12, 30, 60, 120][seed % 6]
+        js = random_scene(seed) if n_inst is None else random_scene(seed, n_inst=n_inst, volume=(seed % 4 != 0))
+        general = seed % 5 == 0
+        if general:
+            os.environ["PATHTRACE_HIP_NO_FASTDIV"] = "1"
+        else:
+            os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
+        try:
+            sc = pt.Scene(text=json.dumps(js), width=96, height=64)
+            r = pt.Renderer(sc, seed=seed)
+        except pt.PathtraceError as e:
+            modes.setdefault("refused", 0)
+            modes["refused"] += 1
+            continue
+        g = r.render(4)
+        gc = r.counters()
+        r.close()
+        osc = oracle.Scene(oracle.sp.load_scene_params(js))
+        o, oc = osc.render_stream(oracle.make_config(96, 64, 4), seed=seed, threads=8)
+        same = (g.view(np.uint32) == o.view(np.uint32)) | (g == o)
+        ok = bool(same.all()) and all(gc[a] == oc[b] for a, b in CTR.items())
+        rays += gc["rays"]
+        modes["general" if general else ("flat" if sc.desc.n_instances <= 24 else "tree")] += 1
+        if not ok:
+            bad.append({"seed": seed, "mismatched": int((~same).sum())})
+        print(f"seed {seed} inst {sc.desc.n_instances} {'ok' if ok else 'MISMATCH'}", file=sys.stderr, flush=True)
+    print(json.dumps({"first_seed": first, "seeds": n, "rays": rays, "sweeps": modes, "mismatching_scenes": bad}))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
