@@ -537,10 +537,10 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
     S.geom_all = 0;
     for (const DOp &op : ops) S.geom_all |= (op.kind >= OP_LEAF_SPHERE);
-    {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_n): every leaf's linear part is
+    {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_fast): a leaf's linear part is
         // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
-        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  Scenes outside it (or
-        // PATHTRACE_HIP_NO_FASTDIV=1, an A/B measurement knob) run the IEEE sweep.
+        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  PATHTRACE_HIP_NO_FASTDIV=1 (an
+        // A/B measurement knob) or an unordered / non-finite node box send the whole scene to the general sweep.
         auto in_range = [](float x, int lo, int hi) {
             uint32_t u;
             memcpy(&u, &x, 4);
@@ -548,16 +548,20 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
         };
         S.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
-        for (int oi = 0; oi < n_general; oi++) {
-            const DOp &op = ops[oi];
+        for (int oi = 0; oi < (int)ops.size(); oi++) {
+            DOp &op = ops[oi];
             if (op.kind == OP_ENTER) {   // world_hit_fast takes min / max of the slab products: the box must be ordered and finite
                 for (int i = 0; i < 3; i++) S.tame &= (op.f[i] <= op.f[i + 3] && std::isfinite(op.f[i]) && std::isfinite(op.f[i + 3])) ? 1 : 0;
                 continue;
             }
             if (op.kind < OP_LEAF_RECT_XY) continue;
-            for (int i = 0; i < 12; i++) S.tame &= in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13) ? 1 : 0;
+            // per leaf: outside the ranges (e.g. the 1e-15 .. 1e-22 residues of rotations composed about several axes) the leaf
+            // keeps its IEEE divisions inside the fast sweep (bit 4 of DOp::slot), everything else of the sweep stays
+            bool leaf_tame = true;
+            for (int i = 0; i < 12; i++) leaf_tame = leaf_tame && in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13);
             const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : ((op.kind == OP_LEAF_BOX || op.kind == OP_LEAF_VOLBOX) ? 6 : 0);   // rect x0 z0 x1 z1 y; box p0 p1; spheres divide the IEEE way
-            for (int i = 0; i < np; i++) S.tame &= in_range(op.g[i], -20, 20) ? 1 : 0;
+            for (int i = 0; i < np; i++) leaf_tame = leaf_tame && in_range(op.g[i], -20, 20);
+            if (!leaf_tame) op.slot |= 16;
         }
     }
     S.textured = S.bg_tex >= 0;
@@ -569,6 +573,27 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     S.n_ops = n_general; S.ops_fast_off = n_general + 1; S.n_ops_fast = n_fast;
     S.n_chain = n_chain;
     if (dev_upload(c, &S.chains, chains)) return -1;
+    {   // the walk's node table (pt_device.h DScene::wnodes): the caller's preorder nodes, a leaf child pointing at the leaf's
+        // DOp of the fast program
+        std::vector<int> leaf_op(sc->n_instances, -1);
+        for (int i = S.ops_fast_off; i < S.ops_fast_off + n_fast; i++)
+            if (ops[i].kind >= OP_LEAF_RECT_XY) leaf_op[ops[i].a] = i;
+        std::vector<float4> wn((size_t)sc->n_nodes * 2);
+        bool ok = true;
+        for (int i = 0; i < sc->n_nodes; i++) {
+            const pt_bvh_node &n = sc->nodes[i];
+            auto child = [&](int ch) { if (ch >= 0) return ch; const int li = leaf_op[~ch]; ok = ok && li >= 0; return ~li; };
+            const int32_t l = child(n.left), r = child(n.right);
+            float lf, rf;
+            memcpy(&lf, &l, 4); memcpy(&rf, &r, 4);
+            wn[2 * i] = make_float4(n.bbox[0], n.bbox[1], n.bbox[2], lf);
+            wn[2 * i + 1] = make_float4(n.bbox[3], n.bbox[4], n.bbox[5], rf);
+        }
+        if (!ok) { set_err("pt_create: a bvh leaf without an op"); return -1; }
+        S.walk = (sc->n_instances > PT_WALK_MIN_INSTANCES && S.tame && !getenv("PATHTRACE_HIP_NO_WALK")) ? 1 : 0;
+        if (getenv("PATHTRACE_HIP_FORCE_WALK") && S.tame) S.walk = 1;   // measurement / test knob: walk small scenes too
+        if (dev_upload(c, &S.wnodes, wn)) return -1;
+    }
     S.n_lights = (int)lights.size(); S.n_vol = nvol;
     S.stack_depth = std::max(max_depth, 1);
     const pt_camera &cm = sc->camera;

@@ -84,14 +84,16 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
     // first half: everything an op needs FIRST (header + node box or instance matrix)
     int32_t kind;
     int32_t a;           // ENTER: skip target;  LEAF: instance index (hit id = a*8 + face)
-    int32_t slot;        // COMBINE: short-stack slot;  LEAF: shape of the inverse's linear part -- 0 general, 1 exactly the
-                         // identity, 2 / 3 / 4 the x / y / z axis is mapped to itself (zero row and column off the diagonal)
+    int32_t slot;        // COMBINE: short-stack slot;  LEAF: bits 0-3 shape of the inverse's linear part -- 0 general, 1 exactly
+                         // the identity, 2 / 3 / 4 the x / y / z axis is mapped to itself (zero row and column off the
+                         // diagonal); bit 4: the leaf's data are outside the precondition of the unscaled division
     int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
     float f[12];
     // second half: primitive parameters, needed only after the ray has been transformed
     float g[16];         // g[i] = "f[12 + i]" of the table above
 };
 #define PT_FLAT_MAX_INSTANCES 24
+#define PT_WALK_MIN_INSTANCES 2048   // measured (tools/walk_bench.py): the lock-step sweep beats the walk up to at least 300 instances
 #define PT_MAX_STACK 8   // short-stack slots per lane and ray held in LDS (tree height <= 8)
 
 struct DCamera {
@@ -126,8 +128,13 @@ struct DScene {
     // ops (pt_kernels.hip world_hit_fast).
     const float4 *chains;
     int32_t n_chain, pad_chain;
-    int32_t tame;                // every matrix entry / bound of the program's leaves is zero or within [2^-20, 2^20]: the
-                                 // sweep may use the unscaled exact division of pt_fdiv.h (pt_kernels.hip world_hit)
+    // Scenes of very many instances (> PT_WALK_MIN_INSTANCES): the per-lane WALK (pt_kernels.hip world_hit_walk) instead of
+    // the sweeps.  wnodes[2 n], wnodes[2 n + 1] = bvh node n: (box min xyz, bits(left)), (box max xyz, bits(right)); a child
+    // >= 0 is a node, < 0 is ~(index into ops of the leaf's DOp in the fast program).
+    const float4 *wnodes;
+    int32_t walk, pad_walk;
+    int32_t tame;                // the fast sweep / walk may run (ordered finite node boxes; not switched off): leaves whose
+                                 // data allow it then use the unscaled exact division of pt_fdiv.h (DOp::slot bit 4 says no)
     DCamera cam;
     float bg[3];
     // config

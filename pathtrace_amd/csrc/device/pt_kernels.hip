@@ -475,7 +475,7 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
             // (1*x + 0*y) + 0*z == x; only the sign of a zero component can differ, which no comparison below can see
             // (+-inf t is rejected either way, 0/0 is NaN either way).  A wave holding any non-finite ray (0*inf = NaN
             // would spread across components) takes the general path.
-            const bool ident = (op_slot == 1) && all_finite;
+            const bool ident = ((op_slot & 15) == 1) && all_finite;
             const v3 Al = ident ? V(m[3] + A.x, m[7] + A.y, m[11] + A.z) : xf_point(m, A);
 #define XF_DIR(b) (ident ? (b) : xf_linear(m, (b)))
             if (kind <= OP_LEAF_RECT_YZ) {   // the three rect alignments first: the most frequent leaf (rect::hit primitive.h:186-225)
@@ -658,7 +658,8 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
     for (int pc = 0; pc < n_ops; ++pc) {
         const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&prog[pc]);
         const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&prog[pc]) + 1);
-        const int kind = w0[0], op_a = w0[1], pat = w0[2];
+        const int kind = w0[0], op_a = w0[1], pat = w0[2] & 15;
+        const bool op_ieee = (w0[2] & 16) != 0;    // this leaf's data are outside the unscaled division's precondition
         const int op_id_base = op_a * 8;
         const float pcf = __int_as_float(w0[3]);   // (float)pc, stored by the host (pt_context.cpp)
 #define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
@@ -704,9 +705,23 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 _Pragma("unroll") for (int r = 0; r < NR; r++)                                                               \
                     e[r] = rect_excess_fast<PLANE>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl[r], T_MIN, T_MAX, fdiv_rcp(Bl[r].DPL), t[r]); \
             }
-            if (kind == OP_LEAF_RECT_XY) { asm volatile("; rect xy"); RECT_BODY(0, z) }
+#define RECT_BODY_IEEE(PLANE)                                                                                          \
+            {                                                                                                                \
+                float ox, opl, oz;                                                                                           \
+                rect_axes<PLANE>(Al, ox, opl, oz);                                                                           \
+                const float num = q1[1] - opl;                                                                               \
+                _Pragma("unroll") for (int r = 0; r < NR; r++)                                                               \
+                    e[r] = rect_excess<PLANE>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl[r], T_MIN, T_MAX, t[r]);             \
+            }
+            if (op_ieee) {
+                if (kind == OP_LEAF_RECT_XY) { asm volatile("; rect xy ieee"); RECT_BODY_IEEE(0) }
+                else if (kind == OP_LEAF_RECT_YZ) { asm volatile("; rect yz ieee"); RECT_BODY_IEEE(2) }
+                else { asm volatile("; rect xz ieee"); RECT_BODY_IEEE(1) }
+            }
+            else if (kind == OP_LEAF_RECT_XY) { asm volatile("; rect xy"); RECT_BODY(0, z) }
             else if (kind == OP_LEAF_RECT_YZ) { asm volatile("; rect yz"); RECT_BODY(2, x) }
             else { asm volatile("; rect xz"); RECT_BODY(1, y) }
+#undef RECT_BODY_IEEE
 #undef RECT_BODY
 #pragma unroll
             for (int r = 0; r < NR; r++) FOLD(r, e[r], t[r], op_id_base)
@@ -715,7 +730,8 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
             for (int r = 0; r < NR; r++) {
                 float t;
                 int face;
-                box_hit_fast(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
+                if (op_ieee) box_hit_shared(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
+                else box_hit_fast(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
                 FOLD(r, (face >= 0) ? 0.0f : 1.0f, t, op_id_base + face)
             }
         } else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
@@ -723,8 +739,13 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
             for (int r = 0; r < NR; r++) {
                 float t1v, t2v;
                 int f1, f2;
-                box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
-                box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                if (op_ieee) {
+                    box_hit_shared(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_shared(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                } else {
+                    box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                }
                 bool hit = (f1 >= 0) && (f2 >= 0);
                 chk = __builtin_fmaf(0.0f, t1v, chk);   // a NaN boundary t: let the general sweep decide
                 chk = __builtin_fmaf(0.0f, t2v, chk);
@@ -794,8 +815,109 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
     return is_nanf(chk);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The WALK: World::hit for scenes of many instances (DScene::walk; the sweeps cost O(#ops) per ray whatever the ray
+// hits).  Every lane descends the bvh_node tree on its own -- node boxes and leaf records are per-lane loads, the pending
+// right children sit on a per-lane stack (the general sweep's short-stack area) -- in bvh_node::hit's order, left subtree
+// before right, so the fold of world_hit_fast applies unchanged: closest hit, the later leaf on equal t, a leaf accepted
+// with a NaN t reported for the general sweep.  Leaf arithmetic is world_hit_fast's (tame waves only: unscaled exact
+// division, min / max slabs) with the plain 3x4 transform; "while-while": all lanes first descend to a leaf, then all
+// evaluate their leaves, whatever kinds they are.
+// ------------------------------------------------------------------------------------------------
+DEVI bool world_hit_walk(const DScene &S, bool lane_valid, v3 A, v3 B, uint32_t k0, uint32_t k1, uint32_t vol_dim, Stk stk,
+                         float &out_t, int &out_id)
+{
+    const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
+    const v3 inv = V(fdiv(1.0f, B.x), fdiv(1.0f, B.y), fdiv(1.0f, B.z));   // aabb.h:38
+    const int NONE = (int)0x80000000;
+    float cur_t = FLT_MAX, chk = 0.0f;
+    int cur_id = -1, sp = 0;
+    int cur = lane_valid ? 0 : NONE;   // >= 0: bvh node, < 0 and != NONE: leaf ~(index of its DOp), NONE: this lane is done
+    for (;;) {
+        while (__any(cur >= 0)) {
+            if (cur >= 0) {   // aabb::hit aabb.h:34-53, the slab arithmetic of the fast sweep's ENTER
+                const float4 lo = S.wnodes[2 * cur], hi = S.wnodes[2 * cur + 1];
+                const float ax = (lo.x - A.x) * inv.x, cx = (hi.x - A.x) * inv.x;
+                const float ay = (lo.y - A.y) * inv.y, cy = (hi.y - A.y) * inv.y;
+                const float az = (lo.z - A.z) * inv.z, cz = (hi.z - A.z) * inv.z;
+                const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
+                const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
+                if (tmax <= tmin) {
+                    if (sp > 0) { sp--; cur = __float_as_int(stk.p[(size_t)sp * stk.stride].x); } else cur = NONE;
+                } else {   // bvh.h:36-38: left->hit, then right->hit
+                    stk.p[(size_t)sp * stk.stride] = make_float2(hi.w, 0.0f);
+                    sp++;
+                    cur = __float_as_int(lo.w);
+                }
+            }
+        }
+        if (!__any(cur != NONE)) break;
+        if (cur != NONE) {
+            const float4 *op = reinterpret_cast<const float4 *>(S.ops + ~cur);
+            const float4 w0 = op[0], w1 = op[1], w2 = op[2], w3 = op[3], w4 = op[4], w5 = op[5];
+            const int kind = __float_as_int(w0.x), inst = __float_as_int(w0.y);
+            const bool ieee = (__float_as_int(w0.z) & 16) != 0;   // leaf data outside the unscaled division's precondition
+            const float m[12] = {w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+            const v3 Al = xf_point(m, A);            // instance::hit primitive.h:298-312
+            const v3 Bl = xf_linear(m, B);
+            float t = 0.0f, e = 1.0f;
+            int face = 0;
+            if (kind <= OP_LEAF_RECT_YZ) {           // rect::hit primitive.h:186-225; g = x0 z0 x1 z1 y
+                const int plane = kind - OP_LEAF_RECT_XY;
+                const v3 o = shuffle(Al, plane), d = shuffle(Bl, plane);
+                t = ieee ? (w5.x - o.y) / d.y : fdiv(w5.x - o.y, d.y);
+                const float xh = o.x + t * d.x, zh = o.z + t * d.z;
+                e = fmaxf(fmaxf(T_MIN - t, t - T_MAX), fmaxf(fmaxf(w4.x - xh, xh - w4.z), fmaxf(w4.y - zh, zh - w4.w)));
+            } else if (kind == OP_LEAF_BOX) {
+                const float p0[3] = {w4.x, w4.y, w4.z}, p1[3] = {w4.w, w5.x, w5.y};
+                if (ieee) box_hit_shared(p0, p1, Al, Bl, T_MIN, T_MAX, t, face);
+                else box_hit_fast(p0, p1, Al, Bl, T_MIN, T_MAX, t, face);
+                e = (face >= 0) ? 0.0f : 1.0f;
+            } else if (kind == OP_LEAF_VOLBOX) {     // constant_medium::hit volume.h:29-93 with a box boundary
+                const float p0[3] = {w4.x, w4.y, w4.z}, p1[3] = {w4.w, w5.x, w5.y};
+                float t1v, t2v;
+                int f1, f2;
+                if (ieee) {
+                    box_hit_shared(p0, p1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_shared(p0, p1, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                } else {
+                    box_hit_fast(p0, p1, Al, Bl, -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_fast(p0, p1, Al, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                }
+                chk = __builtin_fmaf(0.0f, t1v, chk);
+                chk = __builtin_fmaf(0.0f, t2v, chk);
+                const float u = rndf(k0, k1, vol_dim + (uint32_t)__float_as_int(w5.w));
+                e = medium_decide((f1 >= 0) && (f2 >= 0), t1v, t2v, Bl, w5.z, u, t) ? 0.0f : 1.0f;
+                face = 0;
+            } else if (kind == OP_LEAF_SPHERE || kind == OP_LEAF_VOLSPHERE) {   // g = center xyz, radius
+                const v3 oc = vsub(Al, V(w4.x, w4.y, w4.z));
+                const float c = vdot(oc, oc) - w4.w * w4.w;
+                if (kind == OP_LEAF_SPHERE) {        // sphere::hit primitive.h:64-95
+                    e = sphere_t(oc, c, Bl, T_MIN, T_MAX, t) ? 0.0f : 1.0f;
+                } else {
+                    float t1v = 0.0f, t2v = 0.0f;
+                    bool hit = sphere_t(oc, c, Bl, -FLT_MAX, FLT_MAX, t1v);
+                    hit = hit && sphere_t(oc, c, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v);
+                    chk = __builtin_fmaf(0.0f, t1v, chk);
+                    chk = __builtin_fmaf(0.0f, t2v, chk);
+                    const float u = rndf(k0, k1, vol_dim + (uint32_t)__float_as_int(w5.w));
+                    e = medium_decide(hit, t1v, t2v, Bl, w5.z, u, t) ? 0.0f : 1.0f;
+                }
+            }                                        // OP_LEAF_NONE: e stays 1
+            const bool take = !(fmaxf(e, t - cur_t) > 0.0f);
+            cur_t = take ? t : cur_t;
+            cur_id = take ? (inst * 8 + face) : cur_id;
+            chk = __builtin_fmaf(0.0f, cur_t, chk);
+            if (sp > 0) { sp--; cur = __float_as_int(stk.p[(size_t)sp * stk.stride].x); } else cur = NONE;
+        }
+    }
+    out_t = (cur_id >= 0) ? cur_t : 0.0f;
+    out_id = cur_id;
+    return is_nanf(chk);
+}
+
 // World::hit for NR rays of one origin: picks the sweep for this wave (wave-uniform, one scalar branch).
-template <int NR, bool GA>
+template <int NR, bool GA, bool WALK = false>
 DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                     const uint32_t (&vol_dim_base)[NR], Stk stk, float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -809,6 +931,12 @@ DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], u
     }
     bool general = true;
     if (S.tame && __all(tame || !lane_valid)) {
+        if constexpr (WALK) {
+            bool redo = false;
+#pragma unroll
+            for (int r = 0; r < NR; r++) redo = world_hit_walk(S, lane_valid, A, B[r], k0, k1, vol_dim_base[r], stk, out_t[r], out_id[r]) || redo;
+            general = __any(redo && lane_valid);
+        } else
         general = __any(world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id) && lane_valid);
 #ifdef PT_DBG_NO_REDO
         general = false;
@@ -1184,7 +1312,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of every live path's ray (integrator.h:192-193)
 // ------------------------------------------------------------------------------------------------
-template <bool GA>
+template <bool GA, bool WALK>
 __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -1232,7 +1360,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
-        world_hit<1, GA>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
+        world_hit<1, GA, WALK>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
         if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
     }
     if (threadIdx.x == 0 && n_rays) {
@@ -1680,7 +1808,7 @@ DEVI void connect_contribution(const DScene &S, v3 hp, v3 ldir, float t, int id,
 }
 
 // NR rays of one hit (they share their origin) are traversed together; light_samples is a multiple of NR.
-template <int NR, bool TEX, bool GA>
+template <int NR, bool TEX, bool GA, bool WALK>
 __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA : PT_CONNECT_WAVES)) void k_connect(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int bounce)
 {
@@ -1732,7 +1860,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
                     coef[k] = V(d.w, e.x, e.y);
                     vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
                 }
-                world_hit<R, GA>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
+                world_hit<R, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
@@ -1746,7 +1874,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
                 const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
                 float t[1];
                 int id[1];
-                world_hit<1, GA>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
+                world_hit<1, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
                 if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
             }
         }
@@ -1788,7 +1916,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_accumulate(DScene S, DStreams st, 
 // ------------------------------------------------------------------------------------------------
 // trace: World::hit for caller-supplied rays (pt_trace_rays), same traversal as k_extend / k_connect
 // ------------------------------------------------------------------------------------------------
-template <int NR, bool GA>
+template <int NR, bool GA, bool WALK>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restrict__ t_ops, DStreams st, long long n, const float *__restrict__ org,
                                                     const float *__restrict__ dir, uint32_t k0, uint32_t k1, uint32_t vol_dim,
                                                     float *t_out, int *id_out)
@@ -1810,7 +1938,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
             B[r] = V(dir[3 * (j * NR + r)], dir[3 * (j * NR + r) + 1], dir[3 * (j * NR + r) + 2]);
             vd[r] = vol_dim + (uint32_t)r * 16u;
         }
-        world_hit<NR, GA>(S, valid, A, B, k0, k1, vd, stk, t, id);
+        world_hit<NR, GA, WALK>(S, valid, A, B, k0, k1, vd, stk, t, id);
         if (valid) {
 #pragma unroll
             for (int r = 0; r < NR; r++) { t_out[j * NR + r] = t[r]; id_out[j * NR + r] = id[r]; }
@@ -1835,8 +1963,12 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    if (S.geom_all) hipLaunchKernelGGL(k_extend<true>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), dim3(PT_BLOCK), lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+#define PT_LAUNCH_EXTEND(GA, WALK) hipLaunchKernelGGL((k_extend<GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
+    if (S.walk) PT_LAUNCH_EXTEND(true, true);
+    else if (S.geom_all) PT_LAUNCH_EXTEND(true, false);
+    else PT_LAUNCH_EXTEND(false, false);
+#undef PT_LAUNCH_EXTEND
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
@@ -1855,11 +1987,13 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     static const int force = getenv("PATHTRACE_HIP_CONNECT_NR") ? atoi(getenv("PATHTRACE_HIP_CONNECT_NR")) : 0;
     int nr = (L % 2 == 0) ? 2 : 1;
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
+    if (S.walk) nr = 1;   // the walk takes its rays one at a time
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
-#define PT_LAUNCH_CONNECT(NR, TEX, GA) hipLaunchKernelGGL((k_connect<NR, TEX, GA>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
-#define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA); else PT_LAUNCH_CONNECT(1, TEX, GA); }
-    if (S.textured) { if (S.geom_all) PT_LAUNCH_CONNECT_NR(true, true) else PT_LAUNCH_CONNECT_NR(true, false) }
+#define PT_LAUNCH_CONNECT(NR, TEX, GA, WALK) hipLaunchKernelGGL((k_connect<NR, TEX, GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
+#define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA, false); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA, false); else PT_LAUNCH_CONNECT(1, TEX, GA, false); }
+    if (S.walk) { if (S.textured) PT_LAUNCH_CONNECT(1, true, true, true); else PT_LAUNCH_CONNECT(1, false, true, true); }
+    else if (S.textured) { if (S.geom_all) PT_LAUNCH_CONNECT_NR(true, true) else PT_LAUNCH_CONNECT_NR(true, false) }
     else { if (S.geom_all) PT_LAUNCH_CONNECT_NR(false, true) else PT_LAUNCH_CONNECT_NR(false, false) }
 #undef PT_LAUNCH_CONNECT_NR
 #undef PT_LAUNCH_CONNECT
@@ -1869,9 +2003,10 @@ void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, cons
 {
     const int blocks = persistent_grid((n + PT_BLOCK - 1) / PT_BLOCK);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
-#define PT_LAUNCH_TRACE(NR, GA) hipLaunchKernelGGL((k_trace<NR, GA>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, st, n, org, dir, k0, k1, vol_dim, t_out, id_out)
-    if (S.geom_all) { if (nr == 4) PT_LAUNCH_TRACE(4, true); else if (nr == 2) PT_LAUNCH_TRACE(2, true); else PT_LAUNCH_TRACE(1, true); }
-    else { if (nr == 4) PT_LAUNCH_TRACE(4, false); else if (nr == 2) PT_LAUNCH_TRACE(2, false); else PT_LAUNCH_TRACE(1, false); }
+#define PT_LAUNCH_TRACE(NR, GA, WALK) hipLaunchKernelGGL((k_trace<NR, GA, WALK>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, st, n, org, dir, k0, k1, vol_dim, t_out, id_out)
+    if (S.walk) { if (nr == 4) PT_LAUNCH_TRACE(4, true, true); else if (nr == 2) PT_LAUNCH_TRACE(2, true, true); else PT_LAUNCH_TRACE(1, true, true); }
+    else if (S.geom_all) { if (nr == 4) PT_LAUNCH_TRACE(4, true, false); else if (nr == 2) PT_LAUNCH_TRACE(2, true, false); else PT_LAUNCH_TRACE(1, true, false); }
+    else { if (nr == 4) PT_LAUNCH_TRACE(4, false, false); else if (nr == 2) PT_LAUNCH_TRACE(2, false, false); else PT_LAUNCH_TRACE(1, false, false); }
 #undef PT_LAUNCH_TRACE
 }
 int launch_grid_max() { return persistent_grid(1ll << 40); }

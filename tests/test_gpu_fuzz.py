@@ -83,13 +83,16 @@ def test_large_instance_counts(oracle):
     assert all(gc[a] == oc[b] for a, b in CTR.items())
     # 300 instances: a tree deeper than the 8 LDS short-stack slots.  The fast sweep folds leaf by leaf and needs no stack;
     # the general sweep (non-tame waves, NaN-t ties) keeps its partial results in a global scratch stack (pt_kernels.hip
-    # stack_of).  Both must reproduce the oracle: once as launched, once with the fast sweep switched off.
+    # stack_of); the per-lane walk (the default above 2048 instances, forced here) keeps its pending children there.  All
+    # three must reproduce the oracle.
     js = random_scene(8, n_inst=300, volume=False)
     osc = oracle.Scene(oracle.sp.load_scene_params(js))
     o, oc = osc.render_stream(oracle.make_config(24, 18, 2, light_samples=2), seed=3, threads=2)
-    for env in (None, "1"):
-        if env:
+    for env in (None, "1", "walk"):   # fast sweep over the tree program / general sweep / per-lane walk
+        if env == "1":
             os.environ["PATHTRACE_HIP_NO_FASTDIV"] = env
+        elif env == "walk":
+            os.environ["PATHTRACE_HIP_FORCE_WALK"] = "1"
         try:
             big = pt.Scene(text=json.dumps(js), width=24, height=18)
             rb = pt.Renderer(big, seed=3, light_samples=2)
@@ -98,6 +101,7 @@ def test_large_instance_counts(oracle):
             rb.close()
         finally:
             os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
+            os.environ.pop("PATHTRACE_HIP_FORCE_WALK", None)
         assert ((bits(g) == bits(o)) | (g == o)).all(), env
         assert all(gc[a] == oc[b] for a, b in CTR.items()), env
 
