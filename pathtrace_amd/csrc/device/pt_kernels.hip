@@ -655,14 +655,15 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
     }
     const DOp *__restrict__ prog = S.ops + S.ops_fast_off;
     const int n_ops = S.n_ops_fast;
+#define OPW(i) ((i) < 16 ? w0[(i)] : w1[(i) - 16])
     for (int pc = 0; pc < n_ops; ++pc) {
         const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&prog[pc]);
         const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&prog[pc]) + 1);
-        const int kind = w0[0], op_a = w0[1], pat = w0[2] & 15;
-        const bool op_ieee = (w0[2] & 16) != 0;    // this leaf's data are outside the unscaled division's precondition
+        const int kind = OPW(0), op_a = OPW(1), pat = OPW(2) & 15;
+        const bool op_ieee = (OPW(2) & 16) != 0;    // this leaf's data are outside the unscaled division's precondition
         const int op_id_base = op_a * 8;
-        const float pcf = __int_as_float(w0[3]);   // (float)pc, stored by the host (pt_context.cpp)
-#define OPF(i) __int_as_float((i) < 12 ? w0[4 + (i)] : w1[(i) - 12])
+        const float pcf = __int_as_float(OPW(3));   // (float)pc, stored by the host (pt_context.cpp)
+#define OPF(i) __int_as_float(OPW(4 + (i)))
         if (kind == OP_ENTER) {
             const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
             const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
@@ -730,8 +731,9 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
             for (int r = 0; r < NR; r++) {
                 float t;
                 int face;
-                if (op_ieee) box_hit_shared(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
-                else box_hit_fast(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face);
+                // two bodies, one per wave (op_ieee is wave-uniform): the empty asm keeps hipcc from computing both and selecting
+                if (op_ieee) { asm volatile("; box ieee"); box_hit_shared(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face); }
+                else { asm volatile("; box fast"); box_hit_fast(q0, q1, Al, Bl[r], T_MIN, T_MAX, t, face); }
                 FOLD(r, (face >= 0) ? 0.0f : 1.0f, t, op_id_base + face)
             }
         } else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
@@ -740,9 +742,11 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 float t1v, t2v;
                 int f1, f2;
                 if (op_ieee) {
+                    asm volatile("; volbox ieee");
                     box_hit_shared(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
                     box_hit_shared(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
                 } else {
+                    asm volatile("; volbox fast");
                     box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
                     box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
                 }
@@ -755,7 +759,7 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 t1v = (t1v < 0) ? 0.0f : t1v;
                 const float dlen = vlen(Bl[r]);
                 const float distance_inside = (t2v - t1v) * dlen;
-                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
                 const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
                 hit = hit && (hit_distance < distance_inside);
                 const float tv = t1v + hit_distance / dlen;
@@ -784,13 +788,14 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 hit = hit && sphere_t(oc, c, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v);
                 chk = __builtin_fmaf(0.0f, t1v, chk);
                 chk = __builtin_fmaf(0.0f, t2v, chk);
-                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
                 hit = medium_decide(hit, t1v, t2v, Bl[r], OPF(18), u, tv);
                 FOLD(r, hit ? 0.0f : 1.0f, tv, op_id_base)
             }
         }
 #undef FOLD
 #undef OPF
+#undef OPW
     }
     if (S.n_chain) {
         // flat program (pt_device.h DScene::chains): below the root no node box was tested on the way.  bvh_node::hit would

@@ -1,12 +1,13 @@
 #!/bin/bash
 set -o pipefail
-mkdir -p gpurun_out
-for g in 1536 3072 4096 4608 6144 9216; do
-for l in 3; do
-PATHTRACE_HIP_GRID=$g PATHTRACE_HIP_LANES=$l timeout -k 10 300 python bench.py --no-cpu-baseline --no-configs > gpurun_out/g_${g}_$l.json 2> gpurun_out/g.err || { tail gpurun_out/g.err; exit 1; }
-python - <<PY
+R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT
+for i in 1 2 3; do
+PATHTRACE_HIP_LIB=$R/pathtrace_amd/lib/libpathtrace_hip_old.so timeout -k 10 300 python bench.py --no-cpu-baseline --no-configs > gpurun_out/old_$i.json 2> gpurun_out/spec.err || { tail gpurun_out/spec.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-configs > gpurun_out/new_$i.json 2> gpurun_out/spec.err || { tail gpurun_out/spec.err; exit 1; }
+done
+python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/g_${g}_$l.json").read().strip().splitlines()[-1])
-print("grid $g lanes $l", d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"])
+for f in ("old_1","new_1","old_2","new_2","old_3","new_3"):
+    d=json.loads(open(f"gpurun_out/{f}.json").read().strip().splitlines()[-1])
+    print(f, d["value"], d["ms_per_step"], d["config"]["framebuffer_sum"])
 PY
-done; done
