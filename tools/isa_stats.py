@@ -51,32 +51,26 @@ def classify(op, args):
     return "other"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="")
-    ap.add_argument("--blocks", action="store_true")
-    ap.add_argument("--flags", default="")
-    ap.add_argument("--src", default=os.path.join(ROOT, "pathtrace_amd", "csrc", "device", "pt_kernels.hip"))
-    ap.add_argument("--keep", default="")
-    args = ap.parse_args()
+KEYS = ("fp2", "fp2s", "v4", "pk", "trans", "salu", "smem", "vmem", "lds", "div*")
+
+
+def analyze(flags="", src=None, keep="", kernel=""):
+    """Compile `src` to gfx950 assembly with the product's flags (+ `flags`) and return one dict per kernel whose demangled
+    name contains `kernel`: name, vgpr, sgpr, scratch, occupancy, sgpr_spills, vgpr_spills, lds, total {class: n},
+    blocks [(label, {class: n})]."""
     from pathtrace_amd import build as ptb
-    flags = [f for f in ptb.FLAGS if f not in ("-shared", "-fPIC")] + args.flags.split()
-    out = args.keep or os.path.join(tempfile.mkdtemp(), "k.s")
-    cmd = [ptb.HIPCC] + flags + ["-S", "--cuda-device-only", args.src, "-o", out]
-    subprocess.run(cmd, check=True)
+    src = src or os.path.join(ROOT, "pathtrace_amd", "csrc", "device", "pt_kernels.hip")
+    fl = [f for f in ptb.FLAGS if f not in ("-shared", "-fPIC", "-ldl")] + flags.split()
+    out = keep or os.path.join(tempfile.mkdtemp(), "k.s")
+    subprocess.run([ptb.HIPCC] + fl + ["-S", "--cuda-device-only", src, "-o", out], check=True)
     text = open(out).read()
+    res = []
     # kernels: from "<sym>:" (a .globl function) to ".Lfunc_end"
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
         sym, body = m.group(1), m.group(2)
         name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().split("(")[0]
-        if args.kernel not in name:
+        if kernel not in name:
             continue
-        meta = {}
-        mm = re.search(r"\.amdhsa_kernel " + re.escape(sym) + r"\n(.*?)\.end_amdhsa_kernel", text, re.S)
-        if mm:
-            for k in ("next_free_vgpr", "next_free_sgpr", "group_segment_fixed_size", "private_segment_fixed_size"):
-                v = re.search(r"\.amdhsa_" + k + r" (\S+)", mm.group(1))
-                meta[k] = v.group(1) if v else "?"
         tail = text[m.end(): m.end() + 3000]
         info = {k: (re.search(r"; " + k + r": (\S+)", tail) or [None, "?"])[1] for k in
                 ("NumSgprs", "NumVgprs", "ScratchSize", "Occupancy", "LDSByteSize")}
@@ -106,15 +100,33 @@ def main():
                 cur[1]["div*"] = cur[1].get("div*", 0) + 1
                 tot["div*"] = tot.get("div*", 0) + 1
         blocks.append(cur)
-        keys = ("fp2", "fp2s", "v4", "pk", "trans", "salu", "smem", "vmem", "lds", "div*")
-        print(f"{name}\n   vgpr {info['NumVgprs']} sgpr {info['NumSgprs']} scratch {info['ScratchSize']} occupancy {info['Occupancy']} "
-              f"sgpr_spills {spills['sgpr_spill_count']} vgpr_spills {spills['vgpr_spill_count']} lds {info['LDSByteSize']}")
-        print("   static: " + "  ".join(f"{k} {tot.get(k, 0)}" for k in keys))
+
+        def num(v):
+            return int(v) if str(v).isdigit() else v
+        res.append({"name": name, "vgpr": num(info["NumVgprs"]), "sgpr": num(info["NumSgprs"]), "scratch": num(info["ScratchSize"]),
+                    "occupancy": num(info["Occupancy"]), "sgpr_spills": num(spills["sgpr_spill_count"]),
+                    "vgpr_spills": num(spills["vgpr_spill_count"]), "lds": num(info["LDSByteSize"]), "total": tot,
+                    "blocks": [(lab, d) for lab, d in blocks]})
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="")
+    ap.add_argument("--blocks", action="store_true")
+    ap.add_argument("--flags", default="")
+    ap.add_argument("--src", default=None)
+    ap.add_argument("--keep", default="")
+    args = ap.parse_args()
+    for k in analyze(args.flags, args.src, args.keep, args.kernel):
+        print(f"{k['name']}\n   vgpr {k['vgpr']} sgpr {k['sgpr']} scratch {k['scratch']} occupancy {k['occupancy']} "
+              f"sgpr_spills {k['sgpr_spills']} vgpr_spills {k['vgpr_spills']} lds {k['lds']}")
+        print("   static: " + "  ".join(f"{c} {k['total'].get(c, 0)}" for c in KEYS))
         if args.blocks:
-            for lab, d in blocks:
-                n = sum(v for k, v in d.items() if k != "div*")
+            for lab, d in k["blocks"]:
+                n = sum(v for c, v in d.items() if c != "div*")
                 if n >= 12:
-                    print(f"      {lab:14s} {n:5d}: " + "  ".join(f"{k} {d.get(k, 0)}" for k in keys if d.get(k, 0)))
+                    print(f"      {lab:14s} {n:5d}: " + "  ".join(f"{c} {d.get(c, 0)}" for c in KEYS if d.get(c, 0)))
 
 
 if __name__ == "__main__":
