@@ -842,6 +842,7 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         b.n_seg_out = b.n_seg; b.seg_cap_out = b.seg_cap;
         b.P = c->P;
         b.sort_shade = getenv("PATHTRACE_HIP_NO_SORT") ? 0 : 1;
+        b.stage_shadow = (c->S.light_samples >= 1 && c->S.light_samples <= PT_STAGE_MAX_SAMPLES && !getenv("PATHTRACE_HIP_NO_STAGE")) ? 1 : 0;
         if (run_batch(c, b)) return -1;
         s += ns;
     }

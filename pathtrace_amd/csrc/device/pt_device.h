@@ -94,6 +94,7 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
 };
 #define PT_FLAT_MAX_INSTANCES 24
 #define PT_WALK_MIN_INSTANCES 2048   // measured (tools/walk_bench.py): the lock-step sweep beats the walk up to at least 300 instances
+#define PT_STAGE_MAX_SAMPLES 4   // 24 bytes x 256 lanes per sample: 24 KB of LDS per workgroup at 4, six workgroups per CU
 #define PT_MAX_STACK 8   // short-stack slots per lane and ray held in LDS (tree height <= 8)
 
 struct DCamera {
@@ -190,7 +191,8 @@ struct DBatch {
     int32_t n_seg, seg_cap;
     int32_t n_seg_out, seg_cap_out;
     int32_t sort_shade;          // k_shade orders each chunk by shading class before shading it (PATHTRACE_HIP_NO_SORT=1: off)
-    int32_t pad_;
+    int32_t stage_shadow;        // k_shade stages a hit's light samples in LDS and gives hits whose samples cannot contribute no
+                                 // shadow record (light_samples <= PT_STAGE_MAX_SAMPLES; PATHTRACE_HIP_NO_STAGE=1: off)
     int64_t P;                   // allocated slots (plane stride of the shadow queue)
     int64_t n_paths;             // npix*ns  (<= P)
 };

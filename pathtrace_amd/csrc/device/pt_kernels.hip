@@ -1441,17 +1441,20 @@ DEVI float material_value_of(int type, float cosine)
 // LM: how the light of an NEE sample is found -- 1: the scene has one light (scalar records), 2: two lights (both records
 // scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
 // of the others.
-template <bool TEX, int LM>
+template <bool TEX, int LM, bool STAGE>
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
-    __shared__ int sh_cnt[2][PT_BLOCK / 64];
-    __shared__ int sh_base[2];
+    __shared__ int sh_cnt[PT_BLOCK / 64];
+    __shared__ int sh_base;
     __shared__ int sh_key[3][PT_BLOCK / 64];
     __shared__ unsigned char sh_perm[PT_BLOCK];
+    // staged shadow records (DBatch::stage_shadow): [light_samples][PT_BLOCK] float4 (direction, coef.x) then float2 (coef.yz),
+    // every lane writes and reads its own column
+    extern __shared__ float4 sh_stage[];
     const int cps = b.seg_cap / PT_BLOCK;
     const int total_chunks = b.n_seg * cps;
     const DQueue q = st.q[qi];
@@ -1465,7 +1468,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     const bool last_bounce = (bounce + 1 >= S.max_bounces);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // path counters: one popcount of a ballot per event and chunk, kept in scalar registers, flushed once per wave
-    unsigned n_miss = 0, n_hit = 0, n_rr = 0, n_emit = 0, n_pdf = 0, n_limit = 0;
+    unsigned n_miss = 0, n_hit = 0, n_rr = 0, n_emit = 0, n_pdf = 0, n_limit = 0, n_dark = 0;
+    constexpr bool stage = STAGE;   // DBatch::stage_shadow picked the instantiation (launch_shade)
+    float4 *const st_d = sh_stage + threadIdx.x;
+    float2 *const st_e = reinterpret_cast<float2 *>(sh_stage + (size_t)L * PT_BLOCK) + threadIdx.x;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
         const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;   // chunk-major, see k_extend
         const int n = q.count[seg];
@@ -1631,39 +1637,48 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 }
             }
         }
-        // ---- compaction: continuation rays -> next path queue, shadow records -> shadow queue.  One ballot per queue,
-        // one LDS exchange and one atomicAdd per workgroup and queue reserve this chunk's ranges in the output segment.
-        const unsigned long long mc = __ballot(cont), ms = __ballot(shadow);
-        n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(ms); n_rr += __popcll(__ballot(ev_rr));
+        // ---- compaction.  Continuation rays -> next path queue: one ballot, one LDS exchange and one atomicAdd per workgroup
+        // reserve this chunk's range in the output segment.  Shadow records -> shadow queue: one atomicAdd per WAVE (below).
+        const unsigned long long mc = __ballot(cont), mh = __ballot(shadow);
+        n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(mh); n_rr += __popcll(__ballot(ev_rr));
         n_emit += __popcll(__ballot(ev_emit)); n_pdf += __popcll(__ballot(ev_pdf)); n_limit += __popcll(__ballot(ev_limit));
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (lane == 0) { sh_cnt[0][wave] = __popcll(mc); sh_cnt[1][wave] = __popcll(ms); }
+        if (lane == 0) sh_cnt[wave] = __popcll(mc);
         __syncthreads();
-        int off_c = __popcll(mc & below), off_s = __popcll(ms & below), tot_c = 0, tot_s = 0;
+        int off_c = __popcll(mc & below), tot_c = 0;
 #pragma unroll
         for (int w = 0; w < PT_BLOCK / 64; w++) {
-            const int cc = sh_cnt[0][w], cs = sh_cnt[1][w];
-            if (w < wave) { off_c += cc; off_s += cs; }
-            tot_c += cc; tot_s += cs;
+            const int cc = sh_cnt[w];
+            if (w < wave) off_c += cc;
+            tot_c += cc;
         }
-        if (threadIdx.x == 0) {
-            sh_base[0] = tot_c ? atomicAdd(&qo.count[seg_o], tot_c) : 0;
-            sh_base[1] = tot_s ? atomicAdd(&sq.count[seg_o], tot_s) : 0;
-        }
+        if (threadIdx.x == 0) sh_base = tot_c ? atomicAdd(&qo.count[seg_o], tot_c) : 0;
         __syncthreads();   // also orders this chunk's reads of sh_cnt before the next chunk's writes
         if (cont) {
-            const long long o = seg_base_o + sh_base[0] + off_c;
+            const long long o = seg_base_o + sh_base + off_c;
             qo.r0[o] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
             qo.r1[o] = make_float4(nB.x, nB.y, nB.z, new_pdf);
             qo.s0[o] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
             qo.s1[o] = make_float4(att.x, att.y, att.z, __uint_as_float(k1));
         }
+        // A wave reserves its shadow records with one atomicAdd (lane 0, broadcast through an SGPR).
+        auto reserve = [&](bool take) -> long long {
+            const unsigned long long m = __ballot(take);
+            int base_s = 0;
+            if (lane == 0 && m) base_s = atomicAdd(&sq.count[seg_o], __popcll(m));
+            base_s = __builtin_amdgcn_readfirstlane(base_s);
+            return seg_base_o + base_s + __popcll(m & below);
+        };
+        // Staged (light_samples small enough for LDS): the samples go to LDS first and a hit whose samples cannot contribute
+        // -- every coefficient is (+-0, +-0, +-0) or has a NaN: connect would add +-0 or drop it (integrator.h:252-262), the
+        // sum does not change by a bit -- gets no record: its shadow rays are counted, not traced (11 % of the hits of
+        // cornell_box: surfaces facing away from the light, hits on the light).  Otherwise the record is reserved first and
+        // the samples are stored as they are made.
+        bool lit = !stage;
+        long long o = stage ? 0 : reserve(shadow);
         const bool wave_finite = __all(!shadow || (isfinite(hp.x) && isfinite(hp.y) && isfinite(hp.z)));
         if (shadow) {
             // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
-            const long long o = seg_base_o + sh_base[1] + off_s;
-            sq.p0[o] = make_float4(hp.x, hp.y, hp.z, __int_as_float(slot | (pending ? (int)0x80000000 : 0)));
-            if (NV) sq.key[o] = make_uint2(k0, k1);
             const bool att_ok = (double)vlen(att) > 0.0001;   // integrator.h:248
             const v3 ab = vmul(att, beta);
             // the tail every sample shares: MIS weight, attenuation * beta * weight_l / light_pdf_l * dropoff
@@ -1676,8 +1691,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 c = vdivf(c, light_pdf_l);
                 c = vscale(dropoff, c);
                 if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
-                sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
-                sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+                if (stage) {
+                    st_d[k * PT_BLOCK] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
+                    st_e[k * PT_BLOCK] = make_float2(c.y, c.z);
+                    lit = lit || (!v_is_nan(c) && (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f));
+                } else {
+                    sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
+                    sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
+                }
             };
             // A rect light under a pure translation (tl = the inverse's translation), sampled from a finite point: the pdf's
             // ray (ol, ldir) is the one rect::random just built, so rect::pdf_value (primitive.h:151-166) simplifies WITHOUT
@@ -1771,6 +1792,25 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 }
             }
         }
+        if (stage) {
+            o = reserve(shadow && lit);
+            if (shadow && lit) {
+                for (uint32_t k = 0; k < L; k++) {
+                    sq.d[(long long)k * P + o] = st_d[k * PT_BLOCK];
+                    sq.e[(long long)k * P + o] = st_e[k * PT_BLOCK];
+                }
+            }
+            const bool dark = shadow && !lit;
+            n_dark += __popcll(__ballot(dark));
+            if (dark && pending) {   // no record for connect to add the second emitter addition after: nothing comes between
+                const float4 rad = st.radiance[slot], pe = st.pending[slot];
+                st.radiance[slot] = make_float4(rad.x + pe.x, rad.y + pe.y, rad.z + pe.z, 0.0f);
+            }
+        }
+        if (shadow && lit) {
+            sq.p0[o] = make_float4(hp.x, hp.y, hp.z, __int_as_float(slot | (pending ? (int)0x80000000 : 0)));
+            if (NV) sq.key[o] = make_uint2(k0, k1);
+        }
     }
     if (lane == 0) {
         DCounters *cb = counter_bank(st.counters);
@@ -1780,6 +1820,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         if (n_emit) atomicAdd(&cb->term_emitter, (unsigned long long)n_emit);
         if (n_pdf) atomicAdd(&cb->term_pdf, (unsigned long long)n_pdf);
         if (n_limit) atomicAdd(&cb->term_bounce_limit, (unsigned long long)n_limit);
+        if (n_dark) {   // the light_samples shadow rays of every hit without a record: counted like connect counts the traced ones
+            atomicAdd(&cb->rays, (unsigned long long)n_dark * L);
+            atomicAdd(&cb->shadow_rays, (unsigned long long)n_dark * L);
+        }
     }
 }
 
@@ -1978,7 +2022,12 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
-#define PT_LAUNCH_SHADE(TEX, LM) hipLaunchKernelGGL((k_shade<TEX, LM>), grid, block, 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
+    const size_t lds = b.stage_shadow ? (size_t)S.light_samples * PT_BLOCK * (sizeof(float4) + sizeof(float2)) : 0;
+#define PT_LAUNCH_SHADE(TEX, LM)                                                                                                         \
+    do {                                                                                                                                \
+        if (b.stage_shadow) hipLaunchKernelGGL((k_shade<TEX, LM, true>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce); \
+        else hipLaunchKernelGGL((k_shade<TEX, LM, false>), grid, block, 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);                 \
+    } while (0)
     const int lm = S.n_lights == 1 ? 1 : (S.n_lights == 2 ? 2 : 0);   // cornell_box_small_lights 1080p: 2 = 21.1, 0 = 20.8 Grays/s
     if (S.textured) { if (lm == 1) PT_LAUNCH_SHADE(true, 1); else if (lm == 2) PT_LAUNCH_SHADE(true, 2); else PT_LAUNCH_SHADE(true, 0); }
     else { if (lm == 1) PT_LAUNCH_SHADE(false, 1); else if (lm == 2) PT_LAUNCH_SHADE(false, 2); else PT_LAUNCH_SHADE(false, 0); }

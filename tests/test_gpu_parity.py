@@ -99,6 +99,21 @@ def test_bit_exact_config_variants(oracle, scene, kw):
     assert_counters(gc, oc, f"{scene} {kw}")
 
 
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume", "light_test"])
+def test_hits_without_a_shadow_record_change_nothing(oracle, scene, monkeypatch):
+    # k_shade stages a hit's light samples in LDS and writes no shadow record when none of them can contribute (every
+    # coefficient +-0 or NaN: surfaces facing away from the light, hits on the light); their shadow rays are counted, not
+    # traced.  With PATHTRACE_HIP_NO_STAGE=1 every hit gets its record: same bits, same counters, both equal to the oracle.
+    w, h, spp = 128, 72, 8
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=9)
+    staged, c0 = gpu_render(scene, w, h, spp, seed=9)
+    monkeypatch.setenv("PATHTRACE_HIP_NO_STAGE", "1")
+    plain, c1 = gpu_render(scene, w, h, spp, seed=9)
+    assert np.array_equal(bits(staged), bits(plain)) and c0 == c1
+    assert_bit_identical(staged, ref, scene)
+    assert_counters(c0, oc, scene)
+
+
 def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
     # size-independent property: the image is a pure function of (pixel, sample, seed); how the work is cut into
     # batches (max_paths_in_flight), tiles (NaiveSpiral) or sample ranges must not change a single bit.
