@@ -83,6 +83,39 @@ def insts_per_kernel(d):
     return out
 
 
+def wait_states(d):
+    """Pass 5 (PATHTRACE_HIP_LANES=1: every kernel alone on the chip): where a wave's life goes.  SQ_WAVE_CYCLES, SQ_WAIT_*
+    and SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md); WAIT_ANY (parked on s_waitcnt / barrier)
+    + WAIT_INST_ANY (stalled at issue) + ACTIVE_INST_ANY ~ WAVE_CYCLES.  simd_cycles_per_valu_inst = dispatch time x 1024
+    SIMDs x clock / vector instructions: the class-weighted cost of the instruction mix is ~3.5 cycles."""
+    f = find(d, "counter_collection.csv")
+    if not f:
+        return {}
+    acc = defaultdict(lambda: defaultdict(float))
+    dur = defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        k = kname(r["Kernel_Name"])
+        if not k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        dur[k][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    out = {}
+    for k, c in acc.items():
+        t = sum(dur[k].values())
+        wc = max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+        waves = max(c.get("SQ_WAVES", 0.0), 1.0)
+        clock = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t if t > 0 else 0.0
+        out[k] = {"dispatches": len(dur[k]), "seconds": round(t, 6),
+                  "wave_life_cycles": round(4 * wc / waves),
+                  "parked_on_waitcnt_or_barrier": round(c.get("SQ_WAIT_ANY", 0) / wc, 3),
+                  "stalled_at_issue": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                  "executing": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+                  "executing_valu": round(c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
+                  "resident_waves_per_simd": round(4 * wc / (t * clock) / 1024, 2) if clock > 0 else None,
+                  "simd_cycles_per_valu_inst": round(t * 1024 * clock / max(c.get("SQ_INSTS_VALU", 0), 1.0), 2)}
+    return out
+
+
 def main():
     tag, d = sys.argv[1], sys.argv[2]
     out = os.path.join(d, "summary_" + tag)
@@ -112,6 +145,15 @@ def main():
                        "--warmup 1; valu_issue_fraction = wave64 VALU instructions per second / (1024 SIMDs * clock / 2), the FP32 mul/add/fma rate")
         json.dump(ins, open(os.path.join(out, tag + "_instruction_mix.json"), "w"), indent=1)
         print(json.dumps({k: v for k, v in ins.items() if k != "note"}))
+    ws = wait_states(os.path.join(d, tag + "_pmc_wait"))
+    if ws:
+        ws["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                      "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE with PATHTRACE_HIP_LANES=1 (tools/profile_gpu.sh " + tag + " pass 5): every kernel "
+                      "alone on the chip; fractions are of SQ_WAVE_CYCLES, i.e. of a wave's life")
+        json.dump(ws, open(os.path.join(out, tag + "_wait_states.json"), "w"), indent=1)
+        print(json.dumps({k: v for k, v in ws.items() if k != "note"}))
+    if ins:   # instruction totals of the run: the first thing to compare with the previous profile (same workload every time)
+        print("total vector instructions (1e9):", {k: round(v["valu_per_wave"] * v["waves"] / 1e9, 3) for k, v in ins.items() if k != "note"})
     print(json.dumps({k: v for k, v in res.items() if k != "note"}))
     if ks:
         print(open(ks).read()[:1500])
