@@ -284,6 +284,8 @@ static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim
             float hb;
             memcpy(&hb, &head, 4);
             out[0] = make_float4(hb, nl.x, nl.y, nl.z);
+            static_assert(sizeof(DMat) == 48 && PT_FACE_F4 >= 11, "the face table embeds the material record");
+            memcpy(out + 8, &fm, sizeof(DMat));
             if (pr.type == 2) continue;                                     // sphere: the normal depends on the hit point
             face_side(insts[i].inv, nl, out + 1);
             face_side(insts[i].inv, hv3{-nl.x, -nl.y, -nl.z}, out + 4);     // vec3 operator-: (-x, -y, -z)
@@ -295,6 +297,10 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
 {
     if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_materials < 1 || sc->n_nodes < 1) {
         set_err("pt_create: empty scene");
+        return -1;
+    }
+    if (sc->n_instances >= (1 << 25)) {   // hit id = instance * 8 + face below bit 28 (bits 28-29 carry the shading class)
+        set_err("pt_create: %d instances exceed 2^25", sc->n_instances);
         return -1;
     }
     std::vector<DMat> mats(sc->n_materials);
@@ -841,7 +847,12 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
         b.n_seg_out = b.n_seg; b.seg_cap_out = b.seg_cap;
         b.P = c->P;
-        b.sort_shade = getenv("PATHTRACE_HIP_NO_SORT") ? 0 : 1;
+        // the chunk sort of k_shade costs two workgroup barriers per chunk; measured it pays where a hit is
+        // expensive and uneven -- textures, or more than two lights (per-lane light records, sphere lights) -- and not on
+        // the one- and two-light Cornell scenes.  PATHTRACE_HIP_SORT=1 / PATHTRACE_HIP_NO_SORT=1 force it for measurements.
+        b.sort_shade = (c->S.textured || c->S.n_lights > 2) ? 1 : 0;
+        if (getenv("PATHTRACE_HIP_SORT")) b.sort_shade = 1;
+        if (getenv("PATHTRACE_HIP_NO_SORT")) b.sort_shade = 0;
         b.stage_shadow = (c->S.light_samples >= 1 && c->S.light_samples <= PT_STAGE_MAX_SAMPLES && !getenv("PATHTRACE_HIP_NO_STAGE")) ? 1 : 0;
         if (run_batch(c, b)) return -1;
         s += ns;

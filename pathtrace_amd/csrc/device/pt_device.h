@@ -48,9 +48,10 @@ struct DMat {            // 48 bytes
 // both outcomes of rect::hit's facing test (primitive.h:214-222) the world normal  transform.apply_normal(n)
 // (transform3.h:60-63), that normal normalised once more (every consumer -- cos_i integrator.h:201, cosine_pdf pdf.h:18-29,
 // cos_l integrator.h:236 -- calls unit_vector on it) and the onb built from it (helpers.h:127-136).
-// Eight float4 per id:  [0] = bits(mat | ptype << 24 | shading class << 28), local normal xyz;  [1..3] normal kept:  n.xyz nu.x | nu.yz u.xy |
-// u.z v.xyz;  [4..6] normal flipped, same layout;  [7] unused.  A sphere's normal depends on the hit point: ptype says so.
-#define PT_FACE_F4 8
+// Eleven float4 per id:  [0] = bits(mat | ptype << 24 | shading class << 28), local normal xyz;  [1..3] normal kept:  n.xyz nu.x | nu.yz u.xy |
+// u.z v.xyz;  [4..6] normal flipped, same layout;  [7] unused.  [8..10] the face's DMat (the 48 bytes of
+// mats[mat]), so that everything a hit id leads to is one round trip.  A sphere's normal depends on the hit point: ptype says so.
+#define PT_FACE_F4 11
 // texture.h / image.h.  Read with per-lane indices (which child a checker picks depends on the hit point).
 struct DTex {            // 48 bytes
     int32_t type;        // PT_TEX_*

@@ -1335,10 +1335,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     const uint32_t base_dim = DIM_BOUNCE0 + (uint32_t)bounce * dims_per_bounce(S);
     const bool has_vol = S.n_vol > 0;
     unsigned long long n_rays = 0;
+    // the live count of a chunk's segment is fetched one chunk ahead: the scalar load is in flight while the current chunk is
+    // processed, and an empty chunk (the tail of a segment) costs a compare instead of a memory round trip
+    // (chunk, seg) of the next chunk advance by the grid stride without a division per chunk
+    const int g_chunks = (int)gridDim.x / b.n_seg, g_segs = (int)gridDim.x - g_chunks * b.n_seg;
+    int nx_chunk = (int)blockIdx.x / b.n_seg, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg;
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx_seg] : 0;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
         // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
-        const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;
+        const int chunk = nx_chunk, seg = nx_seg;
+        const int n = n_ahead;
+        nx_chunk += g_chunks; nx_seg += g_segs;
+        if (nx_seg >= b.n_seg) { nx_seg -= b.n_seg; nx_chunk++; }
+        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx_seg];
         if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
             // zero the counters this bounce's shade will append to (segment g -> g >> 1; every output segment has an
             // even source).  The other path queue and the shadow queue are idle now: their last readers were the
@@ -1348,7 +1358,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
             st.sq.count[so] = 0;
             if (b.n_seg_out == b.n_seg && seg + 1 < b.n_seg) { st.q[qi ^ 1].count[seg + 1] = 0; st.sq.count[seg + 1] = 0; }
         }
-        const int n = q.count[seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap;
@@ -1366,7 +1375,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
         world_hit<1, GA, WALK>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
-        if (valid) st.hit[pos] = make_float2(t[0], __int_as_float(id[0]));
+        if (valid) {
+            // the hit stream carries the shading class of the face in bits 28-29 of the id (k_shade's sort key): one table
+            // read here, at the end of a chunk, instead of a dependent one at the head of k_shade's
+            int hid = id[0];
+            if (hid >= 0) hid |= __float_as_int(S.faces[(size_t)hid * PT_FACE_F4].x) & (3 << 28);
+            st.hit[pos] = make_float2(t[0], __int_as_float(hid));
+        }
     }
     if (threadIdx.x == 0 && n_rays) {
         atomicAdd(&counter_bank(st.counters)->rays, n_rays);
@@ -1448,8 +1463,6 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
     // stores below never clobber them and keep the wave-uniform table reads on the scalar unit (s_load)
     S.ops = t_ops; S.insts = t_insts; S.prims = t_prims; S.mats = t_mats; S.lights = t_lights; S.emit = t_emit;
-    __shared__ int sh_cnt[PT_BLOCK / 64];
-    __shared__ int sh_base;
     __shared__ int sh_key[3][PT_BLOCK / 64];
     __shared__ unsigned char sh_perm[PT_BLOCK];
     // staged shadow records (DBatch::stage_shadow): [light_samples][PT_BLOCK] float4 (direction, coef.x) then float2 (coef.yz),
@@ -1472,9 +1485,15 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     constexpr bool stage = STAGE;   // DBatch::stage_shadow picked the instantiation (launch_shade)
     float4 *const st_d = sh_stage + threadIdx.x;
     float2 *const st_e = reinterpret_cast<float2 *>(sh_stage + (size_t)L * PT_BLOCK) + threadIdx.x;
-    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
-        const int chunk = c / b.n_seg, seg = c - chunk * b.n_seg;   // chunk-major, see k_extend
-        const int n = q.count[seg];
+    const int g_chunks = (int)gridDim.x / b.n_seg, g_segs = (int)gridDim.x - g_chunks * b.n_seg;   // see k_extend
+    int nx_chunk = (int)blockIdx.x / b.n_seg, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg;
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx_seg] : 0;   // one chunk ahead, see k_extend
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
+        const int chunk = nx_chunk, seg = nx_seg;
+        const int n = n_ahead;
+        nx_chunk += g_chunks; nx_seg += g_segs;
+        if (nx_seg >= b.n_seg) { nx_seg -= b.n_seg; nx_chunk++; }
+        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx_seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap;
@@ -1491,7 +1510,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             int key = 3;
             if (i0 + (int)threadIdx.x < n) {
                 const int hid = __float_as_int(st.hit[seg_base + i0 + threadIdx.x].y);
-                if (hid >= 0) key = (__float_as_int(S.faces[(size_t)hid * PT_FACE_F4].x) >> 28) & 3;
+                if (hid >= 0) key = hid >> 28;   // k_extend put the face's class there
             }
             const unsigned long long m0 = __ballot(key == 0), m1 = __ballot(key == 1), m2 = __ballot(key == 2);
             if (lane == 0) { sh_key[0][wave] = __popcll(m0); sh_key[1][wave] = __popcll(m1); sh_key[2][wave] = __popcll(m2); }
@@ -1535,7 +1554,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             att = V(s1.x, s1.y, s1.z);
             k0 = __float_as_uint(s0.w);
             k1 = __float_as_uint(s1.w);
-            const int id = __float_as_int(h.y);
+            const int id = __float_as_int(h.y) < 0 ? -1 : (__float_as_int(h.y) & 0x0fffffff);   // bits 28-29: shading class
             if (id < 0) {
                 // miss: sum += beta * world->value(u, v, unit_direction) (integrator.h:325-336, world.h:27-30); a constant
                 // background ignores all three.  TAU is "2 * M_PI" unparenthesised (random.h:7), hence the form of u.
@@ -1555,7 +1574,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 ev_miss = true;
             } else {
                 const ShadeHit hi = shade_hit(S, A, B, h.x, id);
-                const DMat m = S.mats[hi.mat];
+                // the face's material record sits in the face table: one round trip for everything a hit id leads to
+                const DMat m = *reinterpret_cast<const DMat *>(S.faces + (size_t)id * PT_FACE_F4 + 8);
                 mat_type = m.type;
                 hp = hi.p;
                 hnu = hi.nu;
@@ -1637,45 +1657,35 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 }
             }
         }
-        // ---- compaction.  Continuation rays -> next path queue: one ballot, one LDS exchange and one atomicAdd per workgroup
-        // reserve this chunk's range in the output segment.  Shadow records -> shadow queue: one atomicAdd per WAVE (below).
-        const unsigned long long mc = __ballot(cont), mh = __ballot(shadow);
-        n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(mh); n_rr += __popcll(__ballot(ev_rr));
+        // ---- compaction: continuation rays -> next path queue, shadow records -> shadow queue.  A wave reserves its range
+        // in the output segment with one ballot and one atomicAdd (lane 0, broadcast through an SGPR): no barrier, the four
+        // waves of the workgroup do not wait for each other.
+        n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(__ballot(shadow)); n_rr += __popcll(__ballot(ev_rr));
         n_emit += __popcll(__ballot(ev_emit)); n_pdf += __popcll(__ballot(ev_pdf)); n_limit += __popcll(__ballot(ev_limit));
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (lane == 0) sh_cnt[wave] = __popcll(mc);
-        __syncthreads();
-        int off_c = __popcll(mc & below), tot_c = 0;
-#pragma unroll
-        for (int w = 0; w < PT_BLOCK / 64; w++) {
-            const int cc = sh_cnt[w];
-            if (w < wave) off_c += cc;
-            tot_c += cc;
-        }
-        if (threadIdx.x == 0) sh_base = tot_c ? atomicAdd(&qo.count[seg_o], tot_c) : 0;
-        __syncthreads();   // also orders this chunk's reads of sh_cnt before the next chunk's writes
-        if (cont) {
-            const long long o = seg_base_o + sh_base + off_c;
-            qo.r0[o] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
-            qo.r1[o] = make_float4(nB.x, nB.y, nB.z, new_pdf);
-            qo.s0[o] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
-            qo.s1[o] = make_float4(att.x, att.y, att.z, __uint_as_float(k1));
-        }
-        // A wave reserves its shadow records with one atomicAdd (lane 0, broadcast through an SGPR).
-        auto reserve = [&](bool take) -> long long {
+        auto reserve = [&](bool take, int32_t *counter) -> long long {
             const unsigned long long m = __ballot(take);
             int base_s = 0;
-            if (lane == 0 && m) base_s = atomicAdd(&sq.count[seg_o], __popcll(m));
+            if (lane == 0 && m) base_s = atomicAdd(counter, __popcll(m));
             base_s = __builtin_amdgcn_readfirstlane(base_s);
             return seg_base_o + base_s + __popcll(m & below);
         };
+        {
+            const long long oc = reserve(cont, &qo.count[seg_o]);
+            if (cont) {
+                qo.r0[oc] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
+                qo.r1[oc] = make_float4(nB.x, nB.y, nB.z, new_pdf);
+                qo.s0[oc] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(k0));
+                qo.s1[oc] = make_float4(att.x, att.y, att.z, __uint_as_float(k1));
+            }
+        }
         // Staged (light_samples small enough for LDS): the samples go to LDS first and a hit whose samples cannot contribute
         // -- every coefficient is (+-0, +-0, +-0) or has a NaN: connect would add +-0 or drop it (integrator.h:252-262), the
         // sum does not change by a bit -- gets no record: its shadow rays are counted, not traced (11 % of the hits of
         // cornell_box: surfaces facing away from the light, hits on the light).  Otherwise the record is reserved first and
         // the samples are stored as they are made.
         bool lit = !stage;
-        long long o = stage ? 0 : reserve(shadow);
+        long long o = stage ? 0 : reserve(shadow, &sq.count[seg_o]);
         const bool wave_finite = __all(!shadow || (isfinite(hp.x) && isfinite(hp.y) && isfinite(hp.z)));
         if (shadow) {
             // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
@@ -1793,7 +1803,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             }
         }
         if (stage) {
-            o = reserve(shadow && lit);
+            o = reserve(shadow && lit, &sq.count[seg_o]);
             if (shadow && lit) {
                 for (uint32_t k = 0; k < L; k++) {
                     sq.d[(long long)k * P + o] = st_d[k * PT_BLOCK];
@@ -1877,9 +1887,15 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
     const CountDiv pick_pdf = count_div(S.n_lights);   // integrator.h:224
     const CountDiv n_samples = count_div(S.light_samples);
     unsigned long long n_rays = 0;
-    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, see k_extend
-        const int chunk = c / b.n_seg_out, seg = c - chunk * b.n_seg_out;   // chunk-major, see k_extend
-        const int n = sq.count[seg];
+    const int g_chunks = (int)gridDim.x / b.n_seg_out, g_segs = (int)gridDim.x - g_chunks * b.n_seg_out;   // see k_extend
+    int nx_chunk = (int)blockIdx.x / b.n_seg_out, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg_out;
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? sq.count[nx_seg] : 0;   // one chunk ahead, see k_extend
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
+        const int chunk = nx_chunk, seg = nx_seg;
+        const int n = n_ahead;
+        nx_chunk += g_chunks; nx_seg += g_segs;
+        if (nx_seg >= b.n_seg_out) { nx_seg -= b.n_seg_out; nx_chunk++; }
+        if (c + (int)gridDim.x < total_chunks) n_ahead = sq.count[nx_seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap_out;

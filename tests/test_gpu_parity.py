@@ -114,6 +114,19 @@ def test_hits_without_a_shadow_record_change_nothing(oracle, scene, monkeypatch)
     assert_counters(c0, oc, scene)
 
 
+@pytest.mark.parametrize("scene", ["cornell_box", "three_orbs"])
+def test_chunk_sort_by_shading_class_changes_nothing(scene, monkeypatch):
+    # k_shade's counting sort of a chunk by shading class is on by default only for textured scenes and scenes of more
+    # than two lights; forced on and off, the image and the counters are the same (per-path arithmetic is lane-free)
+    w, h, spp = 128, 72, 8
+    monkeypatch.setenv("PATHTRACE_HIP_SORT", "1")
+    a, ca = gpu_render(scene, w, h, spp, seed=4)
+    monkeypatch.delenv("PATHTRACE_HIP_SORT")
+    monkeypatch.setenv("PATHTRACE_HIP_NO_SORT", "1")
+    b, cb = gpu_render(scene, w, h, spp, seed=4)
+    assert np.array_equal(bits(a), bits(b)) and ca == cb
+
+
 def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
     # size-independent property: the image is a pure function of (pixel, sample, seed); how the work is cut into
     # batches (max_paths_in_flight), tiles (NaiveSpiral) or sample ranges must not change a single bit.
