@@ -4,8 +4,10 @@
     python tools/fuzz_gpu.py [first_seed] [n_seeds] > gpurun_out/fuzz.json
 
 For every seed: a generated scene (tests/scene_gen.py; varying instance counts so that both the flat program and the tree
-program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_NO_FASTDIV=1 on every 5th seed), rendered at
-96x64x4 on the GPU and by the oracle in stream mode; framebuffer bits and all nine path counters must agree."""
+program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_NO_FASTDIV=1 on every 5th seed; light_samples
+4, 1, 2, 7, 3 by seed so that k_shade's staged and unstaged instantiations both run; the chunk sort forced on for every 3rd
+seed and the staging forced off for every 7th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
+bits and all nine path counters must agree."""
 import json
 import os
 import sys
@@ -38,9 +40,15 @@ def main():
             os.environ["PATHTRACE_HIP_NO_FASTDIV"] = "1"
         else:
             os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
+        ls = [4, 1, 2, 7, 3][seed % 5 if not general else (seed // 5) % 5]
+        for k, on in (("PATHTRACE_HIP_SORT", seed % 3 == 0), ("PATHTRACE_HIP_NO_STAGE", seed % 7 == 0)):
+            if on:
+                os.environ[k] = "1"
+            else:
+                os.environ.pop(k, None)
         try:
             sc = pt.Scene(text=json.dumps(js), width=96, height=64)
-            r = pt.Renderer(sc, seed=seed)
+            r = pt.Renderer(sc, seed=seed, light_samples=ls)
         except pt.PathtraceError as e:
             modes.setdefault("refused", 0)
             modes["refused"] += 1
@@ -49,10 +57,11 @@ def main():
         gc = r.counters()
         r.close()
         osc = oracle.Scene(oracle.sp.load_scene_params(js))
-        o, oc = osc.render_stream(oracle.make_config(96, 64, 4), seed=seed, threads=8)
+        o, oc = osc.render_stream(oracle.make_config(96, 64, 4, light_samples=ls), seed=seed, threads=8)
         same = (g.view(np.uint32) == o.view(np.uint32)) | (g == o)
         ok = bool(same.all()) and all(gc[a] == oc[b] for a, b in CTR.items())
         rays += gc["rays"]
+        modes["staged" if (ls <= 4 and seed % 7 != 0) else "unstaged"] = modes.get("staged" if (ls <= 4 and seed % 7 != 0) else "unstaged", 0) + 1
         modes["general" if general else ("flat" if sc.desc.n_instances <= 24 else "tree")] += 1
         if not ok:
             bad.append({"seed": seed, "mismatched": int((~same).sum())})
