@@ -191,7 +191,7 @@ def main():
     #   strong (default): total work fixed -- K steps of 16 spp over the frame; each rank renders its 1/N of the pixels
     #                     for all K steps, 2 N steps per launch
     #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
-    group = 2 * n
+    group = int(os.environ.get("PT_BENCH_GROUP", "2")) * n
     spp_launch = SPP_PER_STEP * group
     total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
