@@ -40,7 +40,8 @@ namespace ptd {
 #define PT_CONNECT_WAVES 6   // k_connect with two rays per sweep
 #endif
 #ifndef PT_CONNECT_WAVES_GA
-#define PT_CONNECT_WAVES_GA 5   // the same with sphere / constant_medium leaves (96 VGPRs: at 80 it spills 19; with_volume 24.6 -> 26.0 Grays/s)
+#define PT_CONNECT_WAVES_GA 4   // the same with sphere / constant_medium leaves (108 VGPRs; at 96 it spills 12, at 80 19: with_volume 24.9 -> 25.5 Grays/s
+                                // against 5 waves at the end of round 2, three_orbs / light_test equal)
 #endif
 #define PT_PI_D 3.14159265358979323846
 #define PT_PI_F 3.14159274f
