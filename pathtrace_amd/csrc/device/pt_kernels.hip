@@ -1266,6 +1266,12 @@ DEVI void flush_counters(unsigned int *sh_ctr, DCounters *g)
 // ------------------------------------------------------------------------------------------------
 // generate: renderer.h:648-649 jitter + camera::get_ray camera.h:38-47
 // ------------------------------------------------------------------------------------------------
+// The part of a camera path's record that k_generate does not store (bounce 0 only): k1 of the path in `slot`.
+DEVI uint32_t bounce0_k1(const DScene &S, const DBatch &b, int slot)
+{
+    const uint32_t sample = (uint32_t)b.s0 + (uint32_t)slot / (uint32_t)b.npix;   // slot = s_local * npix + pixel, below 2^30
+    return mix_lowbias32(sample ^ S.seed_k1);
+}
 __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DBatch b)
 {
     const int seg = blockIdx.x;
@@ -1301,10 +1307,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
         v3 ver = V(S.cam.vertical[0], S.cam.vertical[1], S.cam.vertical[2]);
         v3 A = vadd(origin, offset);
         v3 B = vsub(vsub(vadd(vadd(llc, vscale(u, hor)), vscale(v, ver)), origin), offset);
+        // A camera path's record is 32 bytes: beta = 1, attenuation = 0 and last_bsdf_pdf = -1 (integrator.h:183) are constants
+        // and k1 follows from the slot (bounce0_state below); k0 rides in the pdf's place.  k_generate is a pure store
+        // stream and k_shade's first launch moves 4.4 TB/s: 64 bytes less per camera sample.
         q.r0[slot] = make_float4(A.x, A.y, A.z, __int_as_float((int)slot));
-        q.r1[slot] = make_float4(B.x, B.y, B.z, -1.0f);                 // last_bsdf_pdf = -1 (integrator.h:183)
-        q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(k0));  // beta = 1
-        q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(k1));  // attenuation = 0
+        q.r1[slot] = make_float4(B.x, B.y, B.z, __uint_as_float(k0));
         st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (threadIdx.x == 0) {
@@ -1370,7 +1377,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         const long long pos = seg_base + (valid ? i : i0);
         float4 r0 = q.r0[pos], r1 = q.r1[pos];
         uint32_t k0 = 0, k1 = 0;
-        if (has_vol) { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
+        if (has_vol) {
+            if (bounce == 0) { k0 = __float_as_uint(r1.w); k1 = bounce0_k1(S, b, __float_as_int(r0.w)); }   // see k_generate
+            else { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
+        }
         float t[1];
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
@@ -1545,12 +1555,18 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         int slot = 0, mat_type = 0;
         if (valid) {
             const long long pos = seg_base + i;
-            const float4 r0 = q.r0[pos], r1 = q.r1[pos], s0 = q.s0[pos], s1 = q.s1[pos];
+            const float4 r0 = q.r0[pos], r1 = q.r1[pos];
+            float4 s0, s1;
             const float2 h = st.hit[pos];
             const v3 A = V(r0.x, r0.y, r0.z);
             const v3 B = V(r1.x, r1.y, r1.z);
             slot = __float_as_int(r0.w);
-            const float last_bsdf_pdf = r1.w;
+            float last_bsdf_pdf = r1.w;
+            if (bounce == 0) {   // a camera path: 32-byte record, the rest are constants (k_generate)
+                s0 = make_float4(1.0f, 1.0f, 1.0f, r1.w);
+                s1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bounce0_k1(S, b, slot)));
+                last_bsdf_pdf = -1.0f;
+            } else { s0 = q.s0[pos]; s1 = q.s1[pos]; }
             beta = V(s0.x, s0.y, s0.z);
             att = V(s1.x, s1.y, s1.z);
             k0 = __float_as_uint(s0.w);
