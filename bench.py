@@ -10,25 +10,35 @@ torch.distributed.run by someone else it runs as one rank (RANK / LOCAL_RANK / W
 
 Workload (BASELINE.json configs[1]): scenes/cornell_box.json, 1920x1080, max_bounces 10, light_samples 4, russian
 roulette on, normal_offset 1e-4.  One *step* = one pass of the hot path over the whole frame at 16 samples per pixel
-(33 M camera samples); the default K = 64 steps is exactly the 1024 spp of configs[1].  Steps are enqueued two per
-wavefront launch (66 M paths per batch).  "ray" = one World::hit query,
-extension + shadow, the reference's own unit (integrator.h:192,247).
+(33 M camera samples); the default K = 64 steps is exactly the 1024 spp of configs[1].
+
+"ray" = one World::hit query, extension + shadow, the reference's own unit (integrator.h:192,247).  `value` counts the
+queries the device PERFORMED (pt_counters::rays_traced).  The reference-equivalent count (`rays`: light_samples shadow
+rays per hit, which is what the reference and the CPU baseline perform for the same image) is ~8 % higher on
+cornell_box, because hits none of whose light samples can contribute get no shadow rays here; its rate is reported
+beside it as `value_reference_equivalent` and is the figure to compare with `cpu_baseline`.
+
+Launch plan (`launch_plan`): a rank's K steps are cut into wavefront batches of at most 66 M paths and at least
+2 x lanes = 6 batches (a context needs three batches in flight to fill the chip), whatever N and K are.
 
 N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
-partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over measured per-tile ray counts
-(pathtrace_amd/distributed.py; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank k mod N).  Every rank renders ITS tiles for all
-K steps with no communication -- 2 N steps per launch, so that a wavefront batch stays at ~66 M paths -- and ONE RCCL
-sum-reduce of the framebuffer to rank 0 ends the timed region.  PT_BENCH_SCALING=weak keeps per-GPU work fixed instead
-(every step renders 16*N spp).
+partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over per-tile ray counts measured
+in one pass (pt_measure_tile_costs; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank k mod N).  Every rank renders ITS tiles
+for all K steps with no communication and ONE RCCL sum-reduce of the framebuffer to rank 0 ends the timed region.
+PT_BENCH_SCALING=weak keeps per-GPU work fixed instead (every step renders 16*N spp).
 
 The timed region holds only GPU work on device-resident data (scene tables + streams live in HBM; there are no host
-buffers on the path) and runs with the library's per-launch event profiling OFF.  The same K steps are then repeated with
-HIP events around every launch (on the stream each kernel is launched on) for the roofline block.  Rank 0 also reports:
-  roofline      dominant kernel: algorithmic bytes / its HIP-event time against 8 TB/s (SURVEY.md 8d byte model), the
-                measured HBM traffic and vector-instruction counts of the same build (rocprofv3 PMC passes, profiles/),
-                and which roof binds
-  configs       short sub-runs of BASELINE configs 3, 4 and config 5's 4K frame on this GPU
-  cpu_baseline  the oracle (CPU restatement, stream mode, all host cores) on a bounded sample of the same workload
+buffers on the path) and runs with the library's per-launch event profiling OFF.  Rank 0 also reports:
+  roofline       from a SERIALISED pass of this very run (one lane: every kernel alone on the chip, HIP events around
+                 every launch on its stream): per kernel the SURVEY.md 8d model bytes / its time against 8 TB/s; top level
+                 = the dominant kernel.  `overlapped` holds the same events with three batches in flight (shared-chip
+                 figures); `pmc` the HBM traffic and vector-instruction counts of rocprofv3 passes under profiles/ when
+                 they were taken on this build of the kernels (same source hash), else null
+  scaling_proxy  N = 1 only: for N' in 2, 4, 8 every rank's tile list is rendered for the same K steps on THIS GPU (the
+                 render has no communication, so rank r's time here is rank r's time at N'): max-over-ranks time,
+                 predicted efficiency T1 / (N' x max T_r), ray imbalance.  The framebuffer reduce is not in it.
+  configs        32-step sub-runs of BASELINE configs 3, 4 and config 5's 4K frame on this GPU
+  cpu_baseline   the oracle (CPU restatement, stream mode, all host cores) on a bounded sample of the same workload
 """
 import argparse
 import json
@@ -46,19 +56,46 @@ if os.environ.get("PT_BENCH_SIZE"):   # e.g. 3840x2160 for BASELINE config 5's f
 SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
 SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
+N_LANES = 3                    # stream lanes of a context (pt_context.cpp; PATHTRACE_HIP_LANES)
+MAX_BATCH_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", str(1920 * 1080 * 32)))   # 66 M path slots x 288 B x 3 lanes = 57 GB
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector ALU roof: 256 CUs x 4 SIMDs, one wave64 FP32 mul/add/fma every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
 # v_fma_f32 2 cycles per wave64 = 157.3 TFLOP/s); other vector instruction classes issue at 4 or more cycles
 VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2
-# SURVEY.md 8(d) byte model, per unit of each kernel
-BYTES_PER_EXT_RAY_EXTEND = 32 + 16          # read ray, write hit
-BYTES_PER_SHADOW_RAY_CONNECT = 48 + 24      # read shadow record, radiance RMW
 PIPELINE_BYTES_PER_RAY_16x9 = 153.0         # whole pipeline, cornell_box 16:9
 
 
-def shade_bytes(E, H, S):
-    # read hit+ray+state 96 per E, write state 48 per H, continuation ray 32 per (E - samples), shadow record 48 per S
-    return 96 * E + 48 * H + 48 * S
+def model_bytes(kernel, d):
+    """SURVEY.md 8(d) byte model per kernel for the counter deltas `d` of a pass (N camera samples, E extension rays,
+    H extension hits, S shadow rays TRACED -- hits without a shadow record move no record bytes): generate writes ray + state 80 per N; extend reads the ray 32
+    and writes the hit 16 per E; shade reads hit + ray + state 96 per E, writes state 48 per H and a shadow record 48 per S;
+    connect reads the record 48 and updates the radiance 24 per S; accumulate is the framebuffer update, 32 per N."""
+    N, E, H, S = d["camera_samples"], d["extension_rays"], d["extension_hits"], d["shadow_rays_traced"]   # records written / read
+    return {"generate": 80 * N, "extend": 48 * E, "shade": 96 * E + 48 * H + 48 * S, "connect": 72 * S, "accumulate": 32 * N}[kernel]
+
+
+def stream_bytes(kernel, d, light_samples, n_launches, pixels):
+    """What THIS implementation's records move per kernel, from the same counter deltas: camera path 32 B + 16 B
+    radiance; hit 8 B; path record 64 B from bounce 1 on; shadow record 16 + 24 L B per hit that has one; radiance / pending
+    updates 32 B.  Smaller than the model where the records were shrunk (generate, accumulate), larger where the model's 48-byte
+    shadow record per RAY stands against 24 B per ray + 16 B per hit here."""
+    N, E, H, S = d["camera_samples"], d["extension_rays"], d["extension_hits"], d["shadow_rays_traced"]
+    lit = S / max(light_samples, 1)
+    ends = d["term_miss"] + d["term_emitter"]
+    return {"generate": 48 * N, "extend": 40 * E,
+            "shade": 40 * E + 32 * (E - N) + 64 * (E - N) + (16 + 24 * light_samples) * lit + 32 * ends,
+            "connect": (16 + 24 * light_samples) * lit + 32 * lit,
+            "accumulate": 16 * N + 32 * pixels * n_launches}[kernel]
+
+
+def launch_plan(my_pixels, total_spp):
+    """Samples per pixel of one wavefront launch: batches of at most MAX_BATCH_PATHS paths, and at least 2 x lanes of them
+    (three in flight fill the chip; with fewer the thin late bounces of the last batches run alone).  Independent of N."""
+    spp_cap = max(1, MAX_BATCH_PATHS // max(my_pixels, 1))
+    want = -(-total_spp // int(os.environ.get("PT_BENCH_TARGET_BATCHES", str(2 * N_LANES))))
+    if os.environ.get("PT_BENCH_GROUP"):   # measurement knob: steps per launch
+        want = SPP_PER_STEP * int(os.environ["PT_BENCH_GROUP"])
+    return max(1, min(spp_cap, want))
 
 
 def self_launch(n, argv):
@@ -75,58 +112,86 @@ def self_launch(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def file_derived_profile(dom):
+def kernel_source_sha16():
+    """Hash of the device sources: a PMC summary under profiles/ describes this build iff it carries the same hash."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_device.h", "pt_fdiv.h"):
+        with open(os.path.join(ROOT, "pathtrace_amd", "csrc", "device", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(dom):
     """HBM traffic and vector-instruction counts of the dominant kernel from the newest committed rocprofv3 PMC summaries
-    (tools/profile_gpu.sh writes them; they are NOT measured by this run and are labelled with their file)."""
+    (tools/profile_gpu.sh writes them).  They are not measured by this run: they are reported only when they were taken on
+    this build of the kernels (kernel_source_sha16 recorded in the file), and under their own key."""
     import glob
-    out = {"traffic": None, "traffic_source": None, "valu": None}
+    sha = kernel_source_sha16()
+    out = {"kernel_source_sha16": sha, "traffic_bytes_per_launch": None, "traffic_source": None, "valu": None,
+           "note": "rocprofv3 --pmc passes of tools/profile_gpu.sh (serialised dispatches), not this run; null = no summary of this build"}
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # rNNx tags sort by round
-    if tfiles:
+    for f in reversed(tfiles):
         try:
-            d = json.load(open(tfiles[-1]))
-            out["traffic"] = d.get(dom, {}).get("hbm_bytes_per_launch")
-            out["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
+            d = json.load(open(f))
         except Exception:
-            pass
-    mixes = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instruction_mix.json")))
-    if mixes:
+            continue
+        if d.get("kernel_source_sha16") == sha and dom in d:
+            out["traffic_bytes_per_launch"] = d[dom].get("hbm_bytes_per_launch")
+            out["traffic_seconds_per_launch"] = d[dom].get("seconds_per_launch")
+            out["traffic_source"] = "profiles/" + os.path.basename(f)
+            break
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instruction_mix.json")))):
         try:
-            mk = json.load(open(mixes[-1])).get(dom)
-            if mk:
-                out["valu"] = {"valu_per_wave": mk["valu_per_wave"], "salu_over_valu": mk["salu_over_valu"],
-                               "valu_insts_per_s_profiled": mk["valu_insts_per_s"],
-                               "source": "profiles/" + os.path.basename(mixes[-1])}
+            d = json.load(open(f))
         except Exception:
-            pass
+            continue
+        mk = d.get(dom)
+        if d.get("kernel_source_sha16") == sha and mk:
+            out["valu"] = {"valu_per_wave": mk["valu_per_wave"], "salu_over_valu": mk["salu_over_valu"],
+                           "wave_insts_per_s": mk["valu_insts_per_s"], "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
+                           "frac": round(mk["valu_insts_per_s"] / VALU_PEAK_WAVE_INSTS, 4),
+                           "source": "profiles/" + os.path.basename(f)}
+            break
     return out
 
 
 def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
-    """A short run of another BASELINE configuration on this GPU: Mrays/s (unprofiled), rays per camera sample, dominant kernel."""
+    """Another BASELINE configuration on this GPU: Mrays/s (unprofiled, `steps` steps), rays per camera sample, and the
+    kernel times of a short serialised pass (one lane)."""
     scene = pt.Scene(os.path.join(ROOT, "scenes", scene_file), w, h)
-    r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=w * h * spp_step)
-    r.render_async(0, spp_step)
+    total = spp_step * steps
+    spp_launch = launch_plan(w * h, total)
+    r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=min(w * h * spp_launch, MAX_BATCH_PATHS))
+
+    def run(s0, s1):
+        s = s0
+        while s < s1:
+            e = min(s + spp_launch, s1)
+            r.render_async(s, e)
+            s = e
+    run(0, spp_launch)
     r.wait()
     r.clear()
     t0 = time.perf_counter()
-    for i in range(steps):
-        r.render_async(i * spp_step, (i + 1) * spp_step)
+    run(0, total)
     r.wait()
     dt = time.perf_counter() - t0
     c = r.counters()
+    r.set_lanes(1)
     r.set_profiling(True)
-    for i in range(steps, steps + 2):
-        r.render_async(i * spp_step, (i + 1) * spp_step)
+    run(total, total + spp_launch)
     r.wait()
     kt = r.kernel_times()
     dom = max(("extend", "shade", "connect"), key=lambda k: kt[k]["ms"])
     r.close()
     scene.close()
-    return {"config": name, "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp",
-            "value": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
-            "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
+    return {"config": name, "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp, {spp_launch} spp per launch",
+            "value": round(c["rays_traced"] / dt / 1e6, 2), "value_reference_equivalent": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
+            "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4),
+            "traced_share": round(c["rays_traced"] / max(c["rays"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
             "dominant_kernel": "k_" + dom,
-            "kernel_ms_profiled_2_steps": {k: round(v["ms"], 3) for k, v in kt.items()}}
+            "kernel_ms_serialised_one_launch": {k: round(v["ms"], 3) for k, v in kt.items()}}
 
 
 def main():
@@ -136,6 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
+    ap.add_argument("--no-scaling-proxy", action="store_true")
     ap.add_argument("--scene", default=SCENE)
     args = ap.parse_args()
 
@@ -173,38 +239,40 @@ def main():
     weak = os.environ.get("PT_BENCH_SCALING") == "weak"
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
     from pathtrace_amd.distributed import measure_tile_costs, reduce_framebuffer, tiles_for_rank
+    spiral = pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE)
+    costs = None
+
+    def tile_costs():
+        # scheduling set-up, like the scene upload outside the timed region: one pass of one sample per pixel over the
+        # frame counts the rays of every tile (identical integers on every rank -> the same ownership map everywhere)
+        planner = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=min(WIDTH * HEIGHT, MAX_BATCH_PATHS))
+        c = measure_tile_costs(planner, spiral)
+        planner.close()
+        return c
+
     setup_t0 = time.perf_counter()
     if n == 1:
         my_tiles = [(0, 0, WIDTH, HEIGHT)]
     else:
-        # scheduling set-up, like the scene upload outside the timed region: every rank counts the rays of one sample
-        # per pixel per tile (identical integers on every rank) and derives the same cost-balanced ownership map
-        costs = None
         if os.environ.get("PT_BENCH_ROUND_ROBIN") != "1":
-            planner = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=TILE * TILE)
-            costs = measure_tile_costs(planner, pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE))
-            planner.close()
+            costs = tile_costs()
         my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
     setup_ms = (time.perf_counter() - setup_t0) * 1e3
-    # One launch = `group` steps of this rank's pixels: a wavefront batch of ~W*H*32 = 66 M paths at every N (measured at
-    # N = 1: 33 M-path batches 28.9, 66 M 29.8, 133 M 30.0 Grays/s -- the thin late bounces of a batch cost less per path).
     #   strong (default): total work fixed -- K steps of 16 spp over the frame; each rank renders its 1/N of the pixels
-    #                     for all K steps, 2 N steps per launch
     #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
-    group = int(os.environ.get("PT_BENCH_GROUP", "2")) * n
-    spp_launch = SPP_PER_STEP * group
     total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
-    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=my_pixels * spp_launch)
+    spp_launch = launch_plan(my_pixels, total_spp)
+    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=min(my_pixels * spp_launch, MAX_BATCH_PATHS))
     # render straight into a torch tensor so that the final reduce needs no copy
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
-    def render_range(s0, s1):
+    def render_range(rr, tiles, s0, s1, step):
         s = s0
         while s < s1:
-            e = min(s + spp_launch, s1)
-            r.render_tiles_async(my_tiles, s, e)
+            e = min(s + step, s1)
+            rr.render_tiles_async(tiles, s, e)
             s = e
 
     def sync():
@@ -214,11 +282,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_pass():
+    def timed_pass(spp):
         r.clear()
         sync()
         t0 = time.perf_counter()
-        render_range(0, total_spp)
+        render_range(r, my_tiles, 0, spp, spp_launch)
         r.wait()
         if rehearsal and dist is not None:
             fb_host = fb.cpu()
@@ -231,7 +299,7 @@ def main():
 
     warm_spp = SPP_PER_STEP * args.warmup * (n if weak else 1)
     if warm_spp:
-        render_range(0, warm_spp)
+        render_range(r, my_tiles, 0, warm_spp, spp_launch)
     sync()
     if dist is not None and not rehearsal and args.warmup > 0:
         reduce_framebuffer(fb, dst=0)   # untimed: RCCL sets its rings and kernels up on the first reduce of this shape
@@ -239,79 +307,116 @@ def main():
 
     # ---- the timed region: exactly K steps, per-launch profiling off ----
     r.set_profiling(False)
-    dt = timed_pass()
+    dt = timed_pass(total_spp)
     ctr = r.counters()
     fb_sum = float(fb[..., :3].double().sum().item()) if rank == 0 else 0.0
-    # ---- the same K steps again with HIP events around every launch (roofline block) ----
+    # ---- the same K steps again with HIP events around every launch, three batches in flight (shared-chip figures) ----
     r.set_profiling(True)
-    dt_prof = timed_pass()
+    dt_prof = timed_pass(total_spp)
     kt = r.kernel_times()
+    # ---- a SERIALISED pass for the roofline block: one lane, so every kernel runs alone on the chip and its HIP-event time is
+    # its own; 4 steps (or K if smaller), the same launches as above ----
+    ser_spp = SPP_PER_STEP * min(4, args.steps) * (n if weak else 1)
+    r.set_lanes(1)
+    r.set_profiling(True)
+    dt_ser = timed_pass(ser_spp)
+    kt_ser = r.kernel_times()
+    ctr_ser = r.counters()
     r.set_profiling(False)
+    r.set_lanes(N_LANES if not os.environ.get("PATHTRACE_HIP_LANES") else int(os.environ["PATHTRACE_HIP_LANES"]))
 
     red_dev = "cpu" if rehearsal else f"cuda:{local_rank}"
     rays = torch.tensor([ctr["rays"], ctr["camera_samples"], ctr["extension_rays"], ctr["extension_hits"],
-                         ctr["shadow_rays"]], dtype=torch.float64, device=red_dev)
+                         ctr["shadow_rays"], ctr["rays_traced"], ctr["shadow_rays_traced"]], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt, dt_prof], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    total_rays, total_samples, E, H, S = [float(x) for x in rays.tolist()]
+    total_rays, total_samples, E, H, S, traced_rays, traced_shadow = [float(x) for x in rays.tolist()]
     dt, dt_prof = [float(x) for x in tmax.tolist()]
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the launching streams) ----
-        model_bytes = {
-            "extend": BYTES_PER_EXT_RAY_EXTEND * kt["extend"]["units"],
-            "connect": BYTES_PER_SHADOW_RAY_CONNECT * kt["connect"]["units"],
-            "shade": shade_bytes(ctr["extension_rays"], ctr["extension_hits"], ctr["shadow_rays"]),
-        }
-        dom = max(("extend", "shade", "connect"), key=lambda k: kt[k]["ms"])
-        launches = max(kt[dom]["launches"], 1)
-        avg_ms = kt[dom]["ms"] / launches
-        achieved = (model_bytes[dom] / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        fd = file_derived_profile(dom)
-        # HBM roof from the counters: measured bytes per launch (PMC passes of the same build, profiles/) over this run's
-        # own launch duration
-        hbm_meas = None
-        if fd["traffic"]:
-            g = fd["traffic"] / (avg_ms * 1e-3) / 1e9
-            hbm_meas = {"achieved": round(g, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(g / HBM_PEAK_GBS, 5),
-                        "bytes_per_launch": fd["traffic"], "source": fd["traffic_source"],
-                        "note": "traffic from the PMC passes of tools/profile_gpu.sh (not measured by this run) / this run's HIP-event launch time"}
-        # vector ALU roof: wave64 vector instructions per second of the dominant kernel against one instruction per SIMD
-        # every 2 cycles; instructions per wave come from the PMC pass of the same build, launch time from this run.
-        # A wave processes 64 units (rays) per chunk pass; instructions per unit = valu_per_wave / (units per wave).
-        valu = None
-        if fd["valu"]:
-            v = dict(fd["valu"])
-            v["peak_wave_insts_per_s"] = VALU_PEAK_WAVE_INSTS
-            v["achieved_wave_insts_per_s_profiled_pass"] = v.pop("valu_insts_per_s_profiled")
-            v["frac"] = round(v["achieved_wave_insts_per_s_profiled_pass"] / VALU_PEAK_WAVE_INSTS, 4)
-            v["note"] = ("instruction counts from the serialised PMC pass of tools/profile_gpu.sh (not measured by this run); "
-                         "peak = 1024 SIMDs x 2.4 GHz / 2 cycles, the rate of FP32 mul/add/fma only")
-            valu = v
-        hbm_frac = achieved / HBM_PEAK_GBS
-        bound = "hbm"
-        if valu and valu["frac"] > max(hbm_frac, hbm_meas["frac"] if hbm_meas else 0.0):
-            bound = "valu"
-        roofline = {"bound": bound, "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(hbm_frac, 5), "traffic": fd["traffic"],
-                    "avg_launch_ms": round(avg_ms, 5), "launches": launches,
-                    "bytes_per_launch_model": round(model_bytes[dom] / launches, 1),
-                    "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
-                    "kernel_launches": {k: v["launches"] for k, v in kt.items()},
-                    "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4),
-                    "hbm_measured": hbm_meas,
-                    "valu": valu,
-                    "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
-                    "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)}
+        # ---- roofline: rank 0's own launches of the serialised pass ----
+        ser = {}
+        for k in ("generate", "extend", "shade", "connect", "accumulate"):
+            ms, launches = kt_ser[k]["ms"], max(kt_ser[k]["launches"], 1)
+            mb = model_bytes(k, ctr_ser)
+            gbs = mb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            sb = stream_bytes(k, ctr_ser, 4, max(kt_ser["accumulate"]["launches"], 1), my_pixels)
+            ser[k] = {"ms": round(ms, 4), "launches": launches, "model_bytes": int(mb), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "stream_bytes": int(sb), "stream_GBps": round(sb / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+        dom = max(("extend", "shade", "connect"), key=lambda k: kt_ser[k]["ms"])
+        kernel_ms_sum = sum(v["ms"] for v in kt_ser.values())
+        pmc = pmc_profile(dom)
+        ser_rays = ctr_ser["rays_traced"]
+        roofline = {"bound": "hbm", "kernel": "k_" + dom,
+                    "achieved": ser[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ser[dom]["frac"],
+                    "traffic": pmc["traffic_bytes_per_launch"],
+                    "avg_launch_ms": round(kt_ser[dom]["ms"] / ser[dom]["launches"], 5), "launches": ser[dom]["launches"],
+                    "bytes_per_launch_model": round(ser[dom]["model_bytes"] / ser[dom]["launches"], 1),
+                    "how": "achieved = SURVEY 8d model bytes of the dominant kernel over its launches / their summed HIP-event time, "
+                           "both from the serialised pass below (one lane: the kernel has the chip to itself)",
+                    "serialised": {"steps": ser_spp // SPP_PER_STEP, "spp": ser_spp, "lanes": 1, "wall_ms": round(dt_ser * 1e3, 3),
+                                   "kernel_ms_sum": round(kernel_ms_sum, 3), "kernels": ser,
+                                   "pipeline_model_GBps": round(sum(v["model_bytes"] for v in ser.values()) / (kernel_ms_sum * 1e-3) / 1e9, 1) if kernel_ms_sum > 0 else None,
+                                   "Mrays_per_s_traced": round(ser_rays / dt_ser / 1e6, 1)},
+                    "overlapped": {"note": f"{N_LANES} batches in flight: launches share the chip, their event times overlap and sum to more than the wall time",
+                                   "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
+                                   "kernel_launches": {k: v["launches"] for k, v in kt.items()},
+                                   "profiled_pass_ms_per_step": round(dt_prof / args.steps * 1e3, 4),
+                                   "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
+                                   "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)},
+                    "pmc": pmc}
+        if pmc["valu"] and pmc["valu"]["frac"] > roofline["frac"]:
+            roofline["bound"] = "valu"   # the vector-issue share of the same kernel (PMC pass of this build) exceeds its HBM share
+
+        # ---- strong-scaling proxy on this one GPU (the render has no communication: rank r's time here is rank r's time at N) ----
+        proxy = None
+        if n == 1 and not args.no_scaling_proxy and not weak:
+            proxy = {"note": "every rank's tile list of an N'-rank run rendered on this GPU for the same K steps with that run's launch plan; "
+                             "T1 = this run's timed region; the RCCL framebuffer reduce (33 MB at 1080p) and host-side launch contention "
+                             "between processes are not in it", "T1_ms": round(dt * 1e3, 3), "by_n": []}
+            p0 = time.perf_counter()
+            costs = costs or tile_costs()
+            proxy["planner_ms"] = round((time.perf_counter() - p0) * 1e3, 1)
+            if os.environ.get("PT_BENCH_PROXY_DETAIL"):
+                proxy["tile_costs"] = costs
+                proxy["tiles"] = spiral
+            for np_ in (2, 4, 8):
+                strat = os.environ.get("PT_BENCH_PARTITION", "lpt")
+                lists = [tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, q, np_, None if strat == "rr" else costs, strat) for q in range(np_)]
+                pix = [sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in tl) for tl in lists]
+                plans = [launch_plan(px, total_spp) for px in pix]
+                rp = pt.Renderer(scene, device=local_rank, seed=0,
+                                 max_paths_in_flight=min(max(px * sl for px, sl in zip(pix, plans)), MAX_BATCH_PATHS))
+                render_range(rp, lists[0], 0, plans[0], plans[0])   # warm-up: one launch
+                rp.wait()
+                times, rr_, cs_, tr_, full_ = [], [], [], [], []
+                for q in range(np_):
+                    rp.clear()
+                    t0 = time.perf_counter()
+                    render_range(rp, lists[q], 0, total_spp, plans[q])
+                    rp.wait()
+                    times.append(time.perf_counter() - t0)
+                    rr_.append(rp.counters()["rays"])
+                    cs_.append(rp.counters()["camera_samples"])
+                    tr_.append(rp.counters()["rays_traced"])
+                    if os.environ.get("PT_BENCH_PROXY_DETAIL"):
+                        full_.append(dict(rp.counters(), tiles=len(lists[q]), pixels=pix[q]))
+                rp.close()
+                proxy["by_n"].append({"n": np_, "max_rank_ms": round(max(times) * 1e3, 3), "min_rank_ms": round(min(times) * 1e3, 3),
+                                      "predicted_efficiency": round(dt / (np_ * max(times)), 4),
+                                      "rays_traced_max_over_mean": round(max(tr_) / (sum(tr_) / np_), 4),
+                                      "spp_per_launch": plans, "batches_per_rank": [-(-total_spp // sl) for sl in plans],
+                                      "rank_ms": [round(t * 1e3, 3) for t in times], "rank_rays": rr_, "rank_camera_samples": cs_, "rank_rays_traced": tr_, "rank_detail": full_ or None,
+                                      "rays_all_ranks": int(sum(rr_))})
 
         configs = None
         if n == 1 and not args.no_configs and not os.environ.get("PT_BENCH_SIZE"):
             configs = []
-            for name, sf, w, h, spp, st in (("configs[2]", "cornell_box_small_lights.json", 1920, 1080, 16, 4),
-                                            ("configs[3]", "cornell_box_with_volume.json", 1920, 1080, 16, 4),
-                                            ("configs[4] frame, 1 GPU", "cornell_box.json", 3840, 2160, 4, 4)):
+            for name, sf, w, h, spp, st in (("configs[2]", "cornell_box_small_lights.json", 1920, 1080, 16, 32),
+                                            ("configs[3]", "cornell_box_with_volume.json", 1920, 1080, 16, 32),
+                                            ("configs[4] frame, 1 GPU", "cornell_box.json", 3840, 2160, 4, 32)):
                 try:
                     configs.append(sub_config(pt, name, sf, w, h, spp, st, local_rank))
                 except Exception as e:   # the headline number does not depend on these
@@ -337,8 +442,8 @@ def main():
             _, mctr = osc_mt.render_mt(mcfg)
             mdt = time.perf_counter() - m0
             cpu = {"value": round(octr["rays"] / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                   "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays), oracle stream mode, "
-                             f"{cores} threads, {cdt:.2f} s wall",
+                   "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays, all of them traced: compare with "
+                             f"value_reference_equivalent), oracle stream mode, {cores} threads, {cdt:.2f} s wall",
                    "reference_order_1thread": {"value": round(mctr["rays"] / mdt / 1e6, 3), "unit": "Mrays/s", "cores": 1,
                                                "sample": f"cornell_box 200x200x16 ({mctr['rays']} rays), oracle mt19937 mode, "
                                                          f"{mdt:.2f} s wall"}}
@@ -363,23 +468,30 @@ def main():
         knobs = {k: v for k, v in os.environ.items() if k.startswith("PATHTRACE_HIP_") or k.startswith("PT_BENCH_")}
         out = {
             "metric": "Mrays/sec + achieved HBM GB/s %peak, cornell_box 1080p@1024spp, 1/2/4/8 GPU",
-            "value": round(total_rays / dt / 1e6, 2),
+            "value": round(traced_rays / dt / 1e6, 2),
             "unit": "Mrays/s",
+            "value_is": "World::hit queries performed by the device (pt_counters.rays_traced) / wall time of the K steps",
+            "value_reference_equivalent": round(total_rays / dt / 1e6, 2),
+            "value_reference_equivalent_is": "the reference's count for the same image (light_samples shadow rays per hit, integrator.h:246-247) / the same time; "
+                                             "hits whose light samples cannot contribute get no shadow rays here",
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"scenes/{os.path.basename(args.scene)} {WIDTH}x{HEIGHT}, iterative NEE path tracing, max_bounces 10, "
                                    f"light_samples 4, russian roulette; step = {SPP_PER_STEP} spp over the frame"
-                                   + (f" x {n} (weak)" if weak else "") + f" (K=64 is 1024 spp), {spp_launch} spp per launch per rank",
-                       "spp_total": total_spp, "camera_samples": int(total_samples), "rays": int(total_rays),
+                                   + (f" x {n} (weak)" if weak else "") + f" (K=64 is 1024 spp), {spp_launch} spp per launch on rank 0 "
+                                   f"({-(-total_spp // spp_launch)} launches)",
+                       "spp_total": total_spp, "camera_samples": int(total_samples), "rays": int(total_rays), "rays_traced": int(traced_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
+                       "shadow_rays_traced_share": round(traced_shadow / max(S, 1), 4),
                        "framebuffer_sum": fb_sum,
                        "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce"),
                        "partition_setup_ms": round(setup_ms, 1),
                        "knobs": knobs},
             "roofline": roofline,
+            "scaling_proxy": proxy,
             "configs": configs,
             "cpu_baseline": cpu,
             "parity": parity,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
@@ -123,6 +123,11 @@ typedef struct pt_counters {
     uint64_t camera_samples;
     uint64_t rays, extension_rays, extension_hits, shadow_rays;
     uint64_t term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
+    /* `rays` and `shadow_rays` count what the reference counts: light_samples shadow rays per hit.  A hit none of whose
+     * light samples can contribute (every coefficient +-0 or NaN: the surface faces away from the light, the hit lies on
+     * the light) is given no shadow record and its shadow rays are NOT traced -- the image is the same bit for bit.  These
+     * two leave such rays out: World::hit queries the device actually performed. */
+    uint64_t rays_traced, shadow_rays_traced;
 } pt_counters;
 
 /* per-kernel device time of the last completed pt_render_async, from HIP events on the render
@@ -176,6 +181,17 @@ int pt_set_device_framebuffer(pt_ctx *ctx, void *device_rgba, size_t bytes);
 void *pt_get_stream(pt_ctx *ctx);
 int pt_set_stream(pt_ctx *ctx, void *hip_stream);
 
+/* Batches rotate over n of the context's stream lanes (default: all it owns, 3).  n = 1 runs the kernels of consecutive
+ * batches one after the other: per-kernel measurements.  Returns the number of lanes the context owns, < 0 on error. */
+int pt_set_lanes(pt_ctx *ctx, int32_t n);
+/* Planner of a tile-partitioned render: rays_out[k] = World::hit queries the device performs (pt_counters::rays_traced:
+ * what a tile costs) for `spp` samples per pixel of rect k, for all rects in one pass (replaces one render + counter
+ * read per tile).  Framebuffer and counters are cleared before and after. */
+int pt_measure_tile_costs(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, int32_t spp, uint64_t *rays_out);
+/* The per-scene build of the traversal sweep: the scene's traversal program as a header text for pt_kernels.hip
+ * (PT_SPEC_HEADER).  Host only (no device needed).  Returns the text length; buf receives it when cap > length.
+ * < 0: the scene has no program to specialise (the generic kernels run). */
+int pt_spec_header(const pt_scene_desc *scene, char *buf, size_t cap);
 int pt_set_profiling(pt_ctx *ctx, int enabled);
 int pt_get_kernel_times(pt_ctx *ctx, pt_kernel_times *out);
 /* debug / parity: radiance of every camera sample of the LAST batch rendered (de_nan not applied):
@@ -195,8 +211,9 @@ int pt_trace_rays(pt_ctx *ctx, int64_t n, int32_t rays_per_origin, const float *
  * The film is cut into block_w x block_h tiles in NaiveSpiral order (queue.h:68-127) and every tile is owned by one
  * device (cost-balanced over measured per-tile ray counts; PATHTRACE_HIP_ROUND_ROBIN=1: tile k -> device k mod n);
  * pt_multi_render_async enqueues each device's tiles as wavefront batches and returns, there is no communication while
- * rendering, and reading the framebuffer sums the per-device framebuffers into the first device -- device-to-device
- * copies + an add kernel, or one RCCL ncclReduce per device (PATHTRACE_HIP_MULTI_RCCL=1).  The result is the
+ * rendering, and reading the framebuffer sums the per-device framebuffers into the first device -- every peer sends only
+ * the pixels of the tiles it owns (packed, one device-to-device copy per peer over its own link, added on the root), or
+ * one RCCL ncclReduce per device (PATHTRACE_HIP_MULTI_RCCL=1).  The result is the
  * single-device image bit for bit.  Replaces the thread fan-out of Tiled::start_render (renderer.h:553-603). */
 typedef struct pt_multi pt_multi;
 pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, int32_t n_devices, const int32_t *devices,
@@ -210,6 +227,8 @@ int pt_multi_snapshot_framebuffer(pt_multi *m, float *rgb_sum, uint64_t *samples
 int pt_multi_get_counters(pt_multi *m, pt_counters *out);                          /* summed over the devices */
 int pt_multi_clear(pt_multi *m);
 int pt_multi_device_count(pt_multi *m);
+int pt_multi_get_device_counters(pt_multi *m, int32_t index, pt_counters *out);     /* of the index-th listed device */
+uint64_t pt_multi_exchange_bytes(pt_multi *m);                                      /* device-to-device bytes of the last framebuffer sum */
 int pt_multi_tile_owners(pt_multi *m, int32_t *owners, int32_t max_tiles);         /* owner index per spiral tile; returns the tile count */
 
 const char *pt_last_error(void);

@@ -76,7 +76,8 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("camera_samples", "rays", "extension_rays", "extension_hits", "shadow_rays",
-                                          "term_miss", "term_rr", "term_emitter", "term_pdf", "term_bounce_limit")]
+                                          "term_miss", "term_rr", "term_emitter", "term_pdf", "term_bounce_limit",
+                                          "rays_traced", "shadow_rays_traced")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -100,11 +101,11 @@ class HostConfig(C.Structure):
 # every symbol include/pathtrace_hip.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
-           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times",
+           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_render_async", "pt_multi_poll", "pt_multi_wait",
            "pt_multi_read_framebuffer", "pt_multi_snapshot_framebuffer", "pt_multi_get_counters", "pt_multi_clear",
-           "pt_multi_device_count", "pt_multi_tile_owners",
+           "pt_multi_device_count", "pt_multi_tile_owners", "pt_multi_get_device_counters", "pt_multi_exchange_bytes",
            "pth_config_from_file", "pth_config_from_json", "pth_scene_from_file", "pth_scene_from_json",
            "pth_scene_desc", "pth_scene_free", "pth_spiral_tiles", "pth_write_ppm", "pth_main"]
 
@@ -140,6 +141,12 @@ def lib():
     L.pt_get_stream.restype = vp
     L.pt_set_stream.argtypes = [vp, vp]
     L.pt_set_profiling.argtypes = [vp, C.c_int]
+    L.pt_set_lanes.argtypes = [vp, C.c_int32]
+    L.pt_measure_tile_costs.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint64)]
+    L.pt_spec_header.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.c_size_t]
+    L.pt_multi_get_device_counters.argtypes = [vp, C.c_int32, C.POINTER(Counters)]
+    L.pt_multi_exchange_bytes.argtypes = [vp]
+    L.pt_multi_exchange_bytes.restype = C.c_uint64
     L.pt_get_kernel_times.argtypes = [vp, C.POINTER(KernelTimes)]
     L.pt_read_last_batch_radiance.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.pt_trace_rays.argtypes = [vp, C.c_int64, C.c_int32, fp, fp, C.c_uint32, C.c_uint32, C.c_uint32, fp, C.POINTER(C.c_int32)]
@@ -251,6 +258,14 @@ class Scene:
         return np.array(out + [c.lens_radius], np.float32)
 
 
+def spec_header(scene: "Scene") -> str:
+    """The scene's traversal program as the header of the per-scene sweep build (host only)."""
+    n = _check(lib().pt_spec_header(C.byref(scene.desc), None, 0), "pt_spec_header")
+    buf = C.create_string_buffer(n + 1)
+    _check(lib().pt_spec_header(C.byref(scene.desc), buf, n + 1), "pt_spec_header")
+    return buf.value.decode()
+
+
 def load_config(path: str = None, text: str = None) -> HostConfig:
     hc = HostConfig()
     if text is not None:
@@ -332,6 +347,19 @@ class Renderer:
     def render(self, samples, rect=None) -> np.ndarray:
         self.render_async(0, samples, rect)
         return self.framebuffer()
+
+    def set_lanes(self, n: int) -> int:
+        """Batches rotate over n stream lanes from now on (1 = kernels of consecutive batches run one after the other);
+        returns the number of lanes the context owns."""
+        return _check(lib().pt_set_lanes(self._h, n), "pt_set_lanes")
+
+    def measure_tile_costs(self, rects, spp: int = 1):
+        """World::hit queries of `spp` samples per pixel of every rect, all rects in one pass (the tile planner)."""
+        flat = [int(v) for r in rects for v in r]
+        arr = (C.c_int32 * len(flat))(*flat)
+        out = (C.c_uint64 * len(rects))()
+        _check(lib().pt_measure_tile_costs(self._h, len(rects), arr, spp, out), "pt_measure_tile_costs")
+        return [int(v) for v in out]
 
     def set_profiling(self, on: bool):
         _check(lib().pt_set_profiling(self._h, int(on)), "pt_set_profiling")
@@ -429,6 +457,15 @@ class MultiRenderer:
 
     def clear(self):
         _check(lib().pt_multi_clear(self._h), "pt_multi_clear")
+
+    def device_counters(self, index: int) -> dict:
+        c = Counters()
+        _check(lib().pt_multi_get_device_counters(self._h, index, C.byref(c)), "pt_multi_get_device_counters")
+        return c.as_dict()
+
+    def exchange_bytes(self) -> int:
+        """Device-to-device bytes moved by the last framebuffer sum."""
+        return int(lib().pt_multi_exchange_bytes(self._h))
 
     def tile_owners(self):
         n = lib().pt_multi_tile_owners(self._h, None, 0)

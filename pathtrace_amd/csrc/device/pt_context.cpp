@@ -25,6 +25,7 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
 void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s);
+void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, unsigned long long *cost, hipStream_t s);
 int launch_grid_max();
 }  // namespace ptd
 
@@ -76,7 +77,8 @@ struct pt_ctx {
     pt_config cfg{};
     DScene S{};
     DStreams st{};
-    int64_t P = 0;       // path slots
+    int64_t P = 0;       // path slots a batch may use
+    int64_t P_phys = 0;  // slots allocated per stream: P + room for a batch cut into segments of seg_cap + 256 (render_group)
     int seg_cap = 4096;
     int n_seg_max = 0;
     std::vector<void *> allocs;
@@ -105,6 +107,11 @@ struct pt_ctx {
     DTile *d_tiles = nullptr;
     size_t d_tiles_cap = 0;
     std::vector<DTile> h_tiles;
+    // tile-cost planner (pt_measure_tile_costs): one word per entry of the tile table while a planner call runs
+    unsigned long long *tally = nullptr, *tally_buf = nullptr;
+    size_t tally_cap = 0;
+    std::vector<int> band_rect;      // rect index of every band of the current pt_render_tiles_async call
+    std::vector<size_t> band_table;  // its index in the tile table
     // profiling
     bool profiling = false;
     std::vector<TimedLaunch> timed;
@@ -293,6 +300,160 @@ static void build_faces(const std::vector<DInst> &insts, const std::vector<DPrim
     }
 }
 
+// The traversal programs of a scene (pt_device.h DOp), built on the host alone: the general program (ENTER / LEAF /
+// COMBINE), behind it the fast program (pt_kernels.hip world_hit_fast), the parent-box table of the flat program and the
+// flags the kernels are picked by.  No device call: pt_spec_source (the per-scene build of the sweep) uses it without a GPU.
+struct HostProgram {
+    std::vector<DOp> ops;          // general program, one padding op, fast program, one padding op
+    std::vector<float4> chains;
+    int n_general = 0, n_fast = 0, n_chain = 0, max_depth = 0, tame = 0, geom_all = 0;
+};
+static int build_program(const pt_scene_desc *sc, HostProgram &hp)
+{
+    if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_nodes < 1) { set_err("pt_create: empty scene"); return -1; }
+    std::vector<int32_t> vol_ordinal(sc->n_instances, -1);   // ordinal among volume instances (stream RNG dimension slot)
+    for (int i = 0, nvol = 0; i < sc->n_instances; i++) {
+        const int pi = sc->instances[i].primitive;
+        if (pi < 0 || pi >= sc->n_primitives) { set_err("pt_create: instance %d: bad primitive", i); return -1; }
+        if (sc->primitives[pi].type == PT_PRIM_VOLUME) vol_ordinal[i] = nvol++;
+    }
+    std::vector<DOp> &ops = hp.ops;
+    int max_depth = 0;
+    // validate child indices first
+    for (int i = 0; i < sc->n_nodes; i++)
+        for (int ch : {sc->nodes[i].left, sc->nodes[i].right})
+            if ((ch >= 0 && (ch >= sc->n_nodes || ch <= i)) || (ch < 0 && ~ch >= sc->n_instances)) {
+                set_err("pt_create: bvh node %d: bad child %d (nodes must be in preorder)", i, ch);
+                return -1;
+            }
+    int pending_push = -1;
+    if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) {
+        set_err("pt_create: malformed BVH, or a constant_medium whose boundary is another constant_medium");
+        return -1;
+    }
+    if (max_depth > 64) {
+        set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds 64", max_depth);
+        return -1;
+    }
+    for (DOp &op : ops)
+        if (op.kind == OP_LEAF_VOLBOX || op.kind == OP_LEAF_VOLSPHERE) { int32_t vo = vol_ordinal[op.a]; memcpy(&op.g[7], &vo, 4); }
+    if (ops.size() >= (1u << 22)) { set_err("pt_create: traversal program too long (%zu ops)", ops.size()); return -1; }
+    ops.push_back(DOp{});   // padding op (never executed)
+    // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
+    // needs neither them nor the pushes), ENTER's skip target re-indexed; stored behind the general program
+    const int n_general = (int)ops.size() - 1;
+    // flat mode (pt_device.h DScene::chains): few instances, shallow tree -> leaves only, ancestors checked afterwards
+    const bool flat = sc->n_instances <= PT_FLAT_MAX_INSTANCES && max_depth <= PT_MAX_STACK && !getenv("PATHTRACE_HIP_NO_FLAT");
+    // (the root's ENTER stays: a wave of camera rays that miss the scene's box leaves the program after one op)
+    auto in_fast = [&](const DOp &o) { return o.kind != OP_COMBINE && !(flat && o.kind == OP_ENTER && &o != &ops[0]); };
+    std::vector<int> fast_index(n_general + 1, 0);
+    for (int i = 0, k = 0; i <= n_general; i++) { fast_index[i] = k; if (i < n_general && in_fast(ops[i])) k++; }
+    const int n_fast = fast_index[n_general];
+    std::vector<float4> &chains = hp.chains;
+    int n_chain = 0;
+    if (flat) {
+        // One box per leaf suffices: its PARENT's.  A node's box is surrounding_box of its children's (aabb.h:55-64:
+        // componentwise fmin / fmax), so every ancestor's box contains the parent's bound for bound, and the slab test is
+        // monotone in the bounds -- (b - o) * invD and the min / max over them only move outwards when a bound does,
+        // rounding included -- hence a ray that hits the parent's box hits every ancestor's.  Leaves hanging off the root
+        // get an all-space box (the root's ENTER op is in the program).
+        n_chain = 1;
+        chains.assign((size_t)sc->n_instances * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (size_t k = 0; k < chains.size(); k += 2) {
+            chains[k] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
+            chains[k + 1] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
+        }
+        std::vector<int> open_nodes;   // ENTER ops whose subtree holds the current op
+        for (int i = 0; i < n_general; i++) {
+            while (!open_nodes.empty() && ops[open_nodes.back()].a <= i) open_nodes.pop_back();
+            if (ops[i].kind == OP_ENTER) open_nodes.push_back(i);
+            else if (ops[i].kind >= OP_LEAF_RECT_XY && open_nodes.size() > 1) {
+                const float *bb = ops[open_nodes.back()].f;
+                chains[(size_t)ops[i].a * 2] = make_float4(bb[0], bb[1], bb[2], 0.f);
+                chains[(size_t)ops[i].a * 2 + 1] = make_float4(bb[3], bb[4], bb[5], 0.f);
+            }
+        }
+    } else chains.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int i = 0; i < n_general; i++) {
+        if (!in_fast(ops[i])) continue;
+        DOp f = ops[i];
+        {   // the fast sweep compares positions as floats: its own index rides in push_slot (unused there), ENTER's target in f[6]
+            const float self = (float)fast_index[i];
+            memcpy(&f.push_slot, &self, 4);
+        }
+        if (f.kind == OP_ENTER) { f.a = fast_index[ops[i].a]; f.f[6] = (float)f.a; }
+        ops.push_back(f);
+    }
+    ops.push_back(DOp{});   // padding
+    hp.geom_all = 0;
+    for (const DOp &op : ops) hp.geom_all |= (op.kind >= OP_LEAF_SPHERE);
+    {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_fast): a leaf's linear part is
+        // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
+        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  PATHTRACE_HIP_NO_FASTDIV=1 (an
+        // A/B measurement knob) or an unordered / non-finite node box send the whole scene to the general sweep.
+        auto in_range = [](float x, int lo, int hi) {
+            uint32_t u;
+            memcpy(&u, &x, 4);
+            u &= 0x7fffffffu;
+            return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
+        };
+        hp.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
+        for (int oi = 0; oi < (int)ops.size(); oi++) {
+            DOp &op = ops[oi];
+            if (op.kind == OP_ENTER) {   // world_hit_fast takes min / max of the slab products: the box must be ordered and finite
+                for (int i = 0; i < 3; i++) hp.tame &= (op.f[i] <= op.f[i + 3] && std::isfinite(op.f[i]) && std::isfinite(op.f[i + 3])) ? 1 : 0;
+                continue;
+            }
+            if (op.kind < OP_LEAF_RECT_XY) continue;
+            // per leaf: outside the ranges (e.g. the 1e-15 .. 1e-22 residues of rotations composed about several axes) the leaf
+            // keeps its IEEE divisions inside the fast sweep (bit 4 of DOp::slot), everything else of the sweep stays
+            bool leaf_tame = true;
+            for (int i = 0; i < 12; i++) leaf_tame = leaf_tame && in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13);
+            const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : ((op.kind == OP_LEAF_BOX || op.kind == OP_LEAF_VOLBOX) ? 6 : 0);   // rect x0 z0 x1 z1 y; box p0 p1; spheres divide the IEEE way
+            for (int i = 0; i < np; i++) leaf_tame = leaf_tame && in_range(op.g[i], -20, 20);
+            if (!leaf_tame) op.slot |= 16;
+        }
+    }
+    hp.n_general = n_general; hp.n_fast = n_fast; hp.n_chain = n_chain; hp.max_depth = max_depth;
+    return 0;
+}
+
+// The scene's fast program as the compile-time table of the per-scene sweep build (pt_kernels.hip PT_SPEC_HEADER): a
+// header text.  Host only.  Returns the text length (without the terminator), or < 0 when the scene has no fast program
+// to specialise (not tame, walked, or too long to unroll).
+#define PT_SPEC_MAX_OPS 96
+static int spec_header_text(const pt_scene_desc *sc, std::string &out)
+{
+    HostProgram hp;
+    if (build_program(sc, hp)) return -1;
+    if (!hp.tame) { set_err("pt_spec_header: the scene does not take the fast sweep"); return -2; }
+    if (hp.n_fast > PT_SPEC_MAX_OPS || sc->n_instances > PT_WALK_MIN_INSTANCES) { set_err("pt_spec_header: %d ops are too many to unroll", hp.n_fast); return -2; }
+    char line[64];
+    out.clear();
+    snprintf(line, sizeof line, "#define PT_SPEC_N %d\n", hp.n_fast);
+    out += line;
+    snprintf(line, sizeof line, "#define PT_SPEC_GA %d\n", hp.geom_all ? 1 : 0);
+    out += line;
+    out += "static __device__ constexpr int kSpecW[PT_SPEC_N][32] = {\n";
+    for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) {
+        int32_t w[32];
+        memcpy(w, &hp.ops[i], 128);
+        out += "  {";
+        for (int k = 0; k < 32; k++) { snprintf(line, sizeof line, "%d%s", w[k], k < 31 ? ", " : ""); out += line; }
+        out += "},\n";
+    }
+    out += "};\n";
+    return (int)out.size();
+}
+extern "C" int pt_spec_header(const pt_scene_desc *scene, char *buf, size_t cap)
+{
+    std::string text;
+    const int n = spec_header_text(scene, text);
+    if (n < 0) return n;
+    if (buf && cap > (size_t)n) memcpy(buf, text.c_str(), (size_t)n + 1);
+    return n;
+}
+
 static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
 {
     if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_materials < 1 || sc->n_nodes < 1) {
@@ -442,74 +603,11 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
                 "unconditionally, world.h:31-35)");
         return -1;
     }
-    std::vector<DOp> ops;
-    int max_depth = 0;
-    // validate child indices first
-    for (int i = 0; i < sc->n_nodes; i++)
-        for (int ch : {sc->nodes[i].left, sc->nodes[i].right})
-            if ((ch >= 0 && (ch >= sc->n_nodes || ch <= i)) || (ch < 0 && ~ch >= sc->n_instances)) {
-                set_err("pt_create: bvh node %d: bad child %d (nodes must be in preorder)", i, ch);
-                return -1;
-            }
-    int pending_push = -1;
-    if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) {
-        set_err("pt_create: malformed BVH, or a constant_medium whose boundary is another constant_medium");
-        return -1;
-    }
-    if (max_depth > 64) {
-        set_err("pt_create: BVH needs %d short-stack slots, the sweep traversal holds 64", max_depth);
-        return -1;
-    }
-    for (DOp &op : ops)
-        if (op.kind == OP_LEAF_VOLBOX || op.kind == OP_LEAF_VOLSPHERE) { int32_t vo = insts[op.a].vol_ordinal; memcpy(&op.g[7], &vo, 4); }
-    if (ops.size() >= (1u << 22)) { set_err("pt_create: traversal program too long (%zu ops)", ops.size()); return -1; }
-    ops.push_back(DOp{});   // padding op (never executed)
-    // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
-    // needs neither them nor the pushes), ENTER's skip target re-indexed; stored behind the general program
-    const int n_general = (int)ops.size() - 1;
-    // flat mode (pt_device.h DScene::chains): few instances, shallow tree -> leaves only, ancestors checked afterwards
-    const bool flat = sc->n_instances <= PT_FLAT_MAX_INSTANCES && max_depth <= PT_MAX_STACK && !getenv("PATHTRACE_HIP_NO_FLAT");
-    // (the root's ENTER stays: a wave of camera rays that miss the scene's box leaves the program after one op)
-    auto in_fast = [&](const DOp &o) { return o.kind != OP_COMBINE && !(flat && o.kind == OP_ENTER && &o != &ops[0]); };
-    std::vector<int> fast_index(n_general + 1, 0);
-    for (int i = 0, k = 0; i <= n_general; i++) { fast_index[i] = k; if (i < n_general && in_fast(ops[i])) k++; }
-    const int n_fast = fast_index[n_general];
-    std::vector<float4> chains;
-    int n_chain = 0;
-    if (flat) {
-        // One box per leaf suffices: its PARENT's.  A node's box is surrounding_box of its children's (aabb.h:55-64:
-        // componentwise fmin / fmax), so every ancestor's box contains the parent's bound for bound, and the slab test is
-        // monotone in the bounds -- (b - o) * invD and the min / max over them only move outwards when a bound does,
-        // rounding included -- hence a ray that hits the parent's box hits every ancestor's.  Leaves hanging off the root
-        // get an all-space box (the root's ENTER op is in the program).
-        n_chain = 1;
-        chains.assign((size_t)sc->n_instances * 2, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (size_t k = 0; k < chains.size(); k += 2) {
-            chains[k] = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, 0.f);
-            chains[k + 1] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0.f);
-        }
-        std::vector<int> open_nodes;   // ENTER ops whose subtree holds the current op
-        for (int i = 0; i < n_general; i++) {
-            while (!open_nodes.empty() && ops[open_nodes.back()].a <= i) open_nodes.pop_back();
-            if (ops[i].kind == OP_ENTER) open_nodes.push_back(i);
-            else if (ops[i].kind >= OP_LEAF_RECT_XY && open_nodes.size() > 1) {
-                const float *bb = ops[open_nodes.back()].f;
-                chains[(size_t)ops[i].a * 2] = make_float4(bb[0], bb[1], bb[2], 0.f);
-                chains[(size_t)ops[i].a * 2 + 1] = make_float4(bb[3], bb[4], bb[5], 0.f);
-            }
-        }
-    } else chains.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int i = 0; i < n_general; i++) {
-        if (!in_fast(ops[i])) continue;
-        DOp f = ops[i];
-        {   // the fast sweep compares positions as floats: its own index rides in push_slot (unused there), ENTER's target in f[6]
-            const float self = (float)fast_index[i];
-            memcpy(&f.push_slot, &self, 4);
-        }
-        if (f.kind == OP_ENTER) { f.a = fast_index[ops[i].a]; f.f[6] = (float)f.a; }
-        ops.push_back(f);
-    }
-    ops.push_back(DOp{});   // padding
+    HostProgram hp;
+    if (build_program(sc, hp)) return -1;
+    std::vector<DOp> &ops = hp.ops;
+    const std::vector<float4> &chains = hp.chains;
+    const int n_general = hp.n_general, n_fast = hp.n_fast, n_chain = hp.n_chain, max_depth = hp.max_depth;
     // emitted radiance by hit id (instance*8 + face): power * emit->value * emit->alpha (material.h:219), the same two
     // float multiplications the kernels would do (this file is compiled with -ffp-contract=off)
     std::vector<float4> emit((size_t)sc->n_instances * 8, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -541,35 +639,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     if (dev_upload(c, &S.tex, texs) || dev_upload(c, &S.texels, texels) || dev_upload(c, &S.ranvec, ranvec) || dev_upload(c, &S.perm, perm))
         return -1;
     S.bg_tex = sc->background_texture < 0 ? -1 : sc->background_texture;
-    S.geom_all = 0;
-    for (const DOp &op : ops) S.geom_all |= (op.kind >= OP_LEAF_SPHERE);
-    {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_fast): a leaf's linear part is
-        // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
-        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  PATHTRACE_HIP_NO_FASTDIV=1 (an
-        // A/B measurement knob) or an unordered / non-finite node box send the whole scene to the general sweep.
-        auto in_range = [](float x, int lo, int hi) {
-            uint32_t u;
-            memcpy(&u, &x, 4);
-            u &= 0x7fffffffu;
-            return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
-        };
-        S.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
-        for (int oi = 0; oi < (int)ops.size(); oi++) {
-            DOp &op = ops[oi];
-            if (op.kind == OP_ENTER) {   // world_hit_fast takes min / max of the slab products: the box must be ordered and finite
-                for (int i = 0; i < 3; i++) S.tame &= (op.f[i] <= op.f[i + 3] && std::isfinite(op.f[i]) && std::isfinite(op.f[i + 3])) ? 1 : 0;
-                continue;
-            }
-            if (op.kind < OP_LEAF_RECT_XY) continue;
-            // per leaf: outside the ranges (e.g. the 1e-15 .. 1e-22 residues of rotations composed about several axes) the leaf
-            // keeps its IEEE divisions inside the fast sweep (bit 4 of DOp::slot), everything else of the sweep stays
-            bool leaf_tame = true;
-            for (int i = 0; i < 12; i++) leaf_tame = leaf_tame && in_range(op.f[i], -44, (i & 3) == 3 ? 20 : 13);
-            const int np = (op.kind <= OP_LEAF_RECT_YZ) ? 5 : ((op.kind == OP_LEAF_BOX || op.kind == OP_LEAF_VOLBOX) ? 6 : 0);   // rect x0 z0 x1 z1 y; box p0 p1; spheres divide the IEEE way
-            for (int i = 0; i < np; i++) leaf_tame = leaf_tame && in_range(op.g[i], -20, 20);
-            if (!leaf_tame) op.slot |= 16;
-        }
-    }
+    S.geom_all = hp.geom_all;
+    S.tame = hp.tame;
     S.textured = S.bg_tex >= 0;
     for (const DMat &m : mats) S.textured |= m.tex >= 0;
     if (dev_upload(c, &S.insts, insts) || dev_upload(c, &S.prims, prims) || dev_upload(c, &S.mats, mats) ||
@@ -632,10 +703,12 @@ static int alloc_streams(pt_ctx *c)
         return -1;
     }
     c->seg_cap = 4096;   // measured on cornell_box 1080p: 1024 -2.4 %, 2048 -1.4 %, 4096 best, 8192 / 16384 -0.3 %
-    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && (v & (v - 1)) == 0) c->seg_cap = v; }
+    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) c->seg_cap = v; }
     c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
     c->P = (int64_t)c->n_seg_max * c->seg_cap;
-    const size_t P = (size_t)c->P;
+    c->n_seg_max += 2;
+    c->P_phys = c->P + 2 * (int64_t)(c->seg_cap + 256);
+    const size_t P = (size_t)c->P_phys;
     const size_t L = (size_t)std::max(c->cfg.light_samples, 1);
     // framebuffer and counters are shared by the lanes
     if (dev_alloc(c, &c->fb_own, (size_t)c->cfg.width * c->cfg.height)) return -1;
@@ -737,7 +810,7 @@ static const DCounters &sum_counters(pt_ctx *c)
     unsigned long long *d = (unsigned long long *)&s;
     for (int b = 0; b < PT_COUNTER_BANKS; b++) {
         const unsigned long long *h = (const unsigned long long *)&c->host_ctr[b];
-        for (int k = 0; k < 10; k++) d[k] += h[k];
+        for (int k = 0; k < PT_N_COUNTERS; k++) d[k] += h[k];
     }
     c->host_sum = s;
     return c->host_sum;
@@ -781,6 +854,19 @@ struct Timer {
     }
 };
 
+// Multiplier of the order in which the persistent workgroups visit the n segments of a queue (pt_kernels.hip ChunkWalk):
+// ~ n / golden ratio, the stride whose multiples mod n are the most evenly spread, made coprime to n so that k -> k * mul
+// mod n is a permutation.  PATHTRACE_HIP_NO_PERM=1 (A/B knob): queue order.
+static int seg_perm(int n)
+{
+    static const bool off = getenv("PATHTRACE_HIP_NO_PERM") != nullptr;
+    if (off || n < 16 || n >= 65536) return 1;   // the kernels form k * mul in 32 bits
+    long long m = llround((double)n * 0.6180339887498949);
+    auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
+    while (gcd(m, n) != 1) m++;
+    return (int)(m % n);
+}
+
 static int run_batch(pt_ctx *c, const DBatch &b)
 {
     const DScene &S = c->S;
@@ -798,8 +884,10 @@ static int run_batch(pt_ctx *c, const DBatch &b)
         static const bool no_merge = getenv("PATHTRACE_HIP_NO_MERGE") != nullptr;
         if (bb.n_seg > 1 && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
         else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
+        bb.perm = seg_perm(bb.n_seg); bb.perm_out = seg_perm(bb.n_seg_out);
         { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm); }
         { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, bb, qi, bounce, sm); }
+        if (c->tally) launch_tally(S, st, bb, qi, c->tally + (b.tiles - c->d_tiles), sm);
         { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, bb, bounce, sm); }
         bb.n_seg = bb.n_seg_out; bb.seg_cap = bb.seg_cap_out;
         qi ^= 1;
@@ -833,6 +921,13 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
 {
     int64_t npix = 0;
     for (size_t i = g0; i < g1; i++) npix += (int64_t)bands[i].w * band_h[i];
+    // what the kernels index with: every batch-local pixel and every path slot of a group stays inside the lane's P slots
+    // and the group's entries of the tile table (k_generate / batch_pixel / bounce0_k1 take these on trust)
+    if (npix < 1 || npix > c->P || tile_off + (g1 - g0) + 1 > c->h_tiles.size()) {
+        set_err("pt_render_tiles_async: internal error: batch group of %lld pixels, %zu bands at table offset %zu (P = %lld, table %zu)",
+                (long long)npix, g1 - g0, tile_off, (long long)c->P, c->h_tiles.size());
+        return -1;
+    }
     const int ns_fit = (int)std::max<int64_t>(1, c->P / npix);
     for (int s = spp_begin; s < spp_end;) {
         const int ns = std::min(ns_fit, spp_end - s);
@@ -842,11 +937,19 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         b.tiles = c->d_tiles + tile_off;
         b.npix = (int)npix;
         b.s0 = s; b.ns = ns;
-        b.seg_cap = c->seg_cap;
+        // Workgroups take the SAME chunk of every segment at the same time (chunk-major order): the addresses in flight are
+        // {g * seg_cap * 16 B}.  When a sample's pixels are a multiple of 2^16 -- e.g. 16 tiles of 128 x 128 -- the live
+        // segments (the pixels over the scene) repeat with a power-of-two period from sample to sample and their addresses
+        // fall on a fraction of the HBM channels: measured 45.5 against 28.3 ms for 2^18 pixels x 54 spp.  One more chunk
+        // per segment breaks the period.  (PATHTRACE_HIP_SEG fixes the size for measurements.)
+        static const bool seg_forced = getenv("PATHTRACE_HIP_SEG") != nullptr;
+        b.seg_cap = (npix % 65536 == 0 && !seg_forced) ? c->seg_cap + 256 : c->seg_cap;
         b.n_paths = npix * ns;
-        b.n_seg = (int)((b.n_paths + c->seg_cap - 1) / c->seg_cap);
+        b.n_seg = (int)((b.n_paths + b.seg_cap - 1) / b.seg_cap);
         b.n_seg_out = b.n_seg; b.seg_cap_out = b.seg_cap;
-        b.P = c->P;
+        b.perm = b.perm_out = 1;
+        b.P = c->P_phys;
+        if ((int64_t)b.n_seg * b.seg_cap > c->P_phys || b.n_seg > c->n_seg_max) { set_err("pt_render_tiles_async: internal error: %d segments of %d slots exceed the streams", b.n_seg, b.seg_cap); return -1; }
         // the chunk sort of k_shade costs two workgroup barriers per chunk; measured it pays where a hit is
         // expensive and uneven -- textures, or more than two lights (per-lane light records, sphere lights) -- and not on
         // the one- and two-light Cornell scenes.  PATHTRACE_HIP_SORT=1 / PATHTRACE_HIP_NO_SORT=1 force it for measurements.
@@ -860,7 +963,7 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
     return 0;
 }
 
-extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end)
+static int render_tiles(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end, bool tally)
 {
     if (!c || !rects || n_rects < 1) { set_err("pt_render_tiles_async: bad argument"); return -1; }
     if (spp_begin < 0 || spp_end <= spp_begin) { set_err("pt_render_tiles_async: bad sample range [%d,%d)", spp_begin, spp_end); return -1; }
@@ -868,6 +971,8 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
     // rects -> bands of at most P pixels each
     std::vector<DTile> bands;
     std::vector<int> band_h;
+    c->band_rect.clear();
+    c->band_table.clear();
     for (int r = 0; r < n_rects; r++) {
         const int x0 = rects[4 * r], y0 = rects[4 * r + 1], x1 = rects[4 * r + 2], y1 = rects[4 * r + 3];
         if (x0 < 0 || y0 < 0 || x1 > c->cfg.width || y1 > c->cfg.height || x0 >= x1 || y0 >= y1) {
@@ -882,6 +987,7 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
             const int hb = std::min(rows_fit, y1 - yb);
             bands.push_back(DTile{x0, yb, w, 0});
             band_h.push_back(hb);
+            c->band_rect.push_back(r);
         }
     }
     // greedy groups of consecutive bands with <= P pixels; tile table = per group [bands..., sentinel]
@@ -895,6 +1001,7 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
         while (j < bands.size() && npix + (int64_t)bands[j].w * band_h[j] <= c->P) {
             DTile t = bands[j];
             t.pix0 = (int)npix;
+            c->band_table.push_back(table.size());
             table.push_back(t);
             npix += (int64_t)bands[j].w * band_h[j];
             j++;
@@ -915,11 +1022,49 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
         HIP_TRY(hipMemcpy(c->d_tiles, table.data(), table.size() * sizeof(DTile), hipMemcpyHostToDevice));
         c->h_tiles = table;
     }
+    c->tally = nullptr;
+    if (tally) {   // pt_measure_tile_costs: one zeroed cost word per table entry, added to by k_tally after every k_extend
+        for (int l = 0; l < c->n_lanes_alloc; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
+        if (table.size() > c->tally_cap) {
+            if (dev_alloc(c, &c->tally_buf, table.size() * 2)) return -1;
+            c->tally_cap = table.size() * 2;
+        }
+        c->tally = c->tally_buf;
+        HIP_TRY(hipMemset(c->tally, 0, table.size() * sizeof(unsigned long long)));
+    }
     for (const Group &g : groups)
-        if (render_group(c, bands, band_h, g.g0, g.g1, g.off, spp_begin, spp_end)) return -1;
+        if (render_group(c, bands, band_h, g.g0, g.g1, g.off, spp_begin, spp_end)) { c->tally = nullptr; return -1; }
     // the last accumulate transitively waited for every earlier accumulate, i.e. for every earlier batch
     HIP_TRY(hipEventRecord(c->done_ev, c->lanes[c->last_lane].stream));
     return 0;
+}
+
+extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end)
+{
+    return render_tiles(c, n_rects, rects, spp_begin, spp_end, false);
+}
+
+extern "C" int pt_wait(pt_ctx *c);
+extern "C" int pt_clear_framebuffer(pt_ctx *c);
+// The planner of a tile-partitioned render: World::hit queries PERFORMED (extension rays + the shadow rays
+// of hits that got a shadow record: pt_counters::rays_traced) for `spp` samples per pixel of every rect, counted per rect
+// in ONE pass over all of them -- the rects are rendered together as ordinary wavefront batches and k_tally attributes
+// every bounce's rays to the rect the path's pixel lies in.  Leaves framebuffer and counters cleared.  Deterministic: the
+// RNG is keyed by pixel and sample.
+extern "C" int pt_measure_tile_costs(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp, uint64_t *rays_out)
+{
+    if (!c || !rects || n_rects < 1 || spp < 1 || !rays_out) { set_err("pt_measure_tile_costs: bad argument"); return -1; }
+    if (pt_clear_framebuffer(c)) return -1;
+    int rc = render_tiles(c, n_rects, rects, 0, spp, true);
+    unsigned long long *dev = c->tally;
+    if (!rc) rc = pt_wait(c);
+    c->tally = nullptr;
+    if (rc) return -1;
+    std::vector<unsigned long long> host(c->h_tiles.size(), 0);
+    HIP_TRY(hipMemcpy(host.data(), dev, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int r = 0; r < n_rects; r++) rays_out[r] = 0;
+    for (size_t k = 0; k < c->band_rect.size(); k++) rays_out[c->band_rect[k]] += host[c->band_table[k]];
+    return pt_clear_framebuffer(c);
 }
 
 extern "C" int pt_render_async(pt_ctx *c, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t spp_begin, int32_t spp_end)
@@ -932,6 +1077,7 @@ extern "C" int pt_render_async(pt_ctx *c, int32_t x0, int32_t y0, int32_t x1, in
 extern "C" int pt_poll(pt_ctx *c, uint64_t *samples_done, uint64_t *rays_done)
 {
     if (!c) { set_err("pt_poll: null ctx"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
     hipError_t e = hipEventQuery(c->done_ev);
     const DCounters &hs = sum_counters(c);
     if (samples_done) *samples_done = hs.camera_samples;
@@ -972,6 +1118,7 @@ static int collect_times(pt_ctx *c)
 extern "C" int pt_wait(pt_ctx *c)
 {
     if (!c) { set_err("pt_wait: null ctx"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));   // every entry point below starts with pt_wait: the context's device is current after it
     for (int l = 0; l < c->n_lanes_alloc; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
     return collect_times(c);
 }
@@ -1039,6 +1186,8 @@ extern "C" int pt_get_counters(pt_ctx *c, pt_counters *out)
     out->rays = d.rays; out->extension_rays = d.ext_rays; out->extension_hits = d.ext_hits; out->shadow_rays = d.shadow_rays;
     out->term_miss = d.term_miss; out->term_rr = d.term_rr; out->term_emitter = d.term_emitter;
     out->term_pdf = d.term_pdf; out->term_bounce_limit = d.term_bounce_limit;
+    out->shadow_rays_traced = d.shadow_rays - d.shadow_untraced;
+    out->rays_traced = d.rays - d.shadow_untraced;
     return 0;
 }
 
@@ -1093,6 +1242,18 @@ extern "C" int pt_set_stream(pt_ctx *c, void *s)
     c->next_lane = 0;
     c->last_lane = -1;
     return 0;
+}
+// Batches rotate over `n` of the context's lanes from now on (1 .. the lanes it owns; PATHTRACE_HIP_LANES at pt_create).
+// n = 1 serialises the kernels of consecutive batches: what a per-kernel measurement needs (bench.py's roofline pass).
+extern "C" int pt_set_lanes(pt_ctx *c, int32_t n)
+{
+    if (!c) { set_err("pt_set_lanes: null ctx"); return -1; }
+    if (pt_wait(c)) return -1;
+    if (n < 1 || n > c->n_lanes_alloc) { set_err("pt_set_lanes: %d outside 1..%d", n, c->n_lanes_alloc); return -1; }
+    if (c->stream != c->own_stream && n != 1) { set_err("pt_set_lanes: a caller-owned stream runs one lane"); return -1; }
+    c->n_lanes = n;
+    c->next_lane = 0;
+    return c->n_lanes_alloc;
 }
 extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
 {

@@ -168,8 +168,11 @@ struct DCounters {       // one bank; padded to 128 B so that banks never share 
     unsigned long long camera_samples;
     unsigned long long rays, ext_rays, ext_hits, shadow_rays;
     unsigned long long term_miss, term_rr, term_emitter, term_pdf, term_bounce_limit;
-    unsigned long long pad[6];
+    unsigned long long shadow_untraced;   // shadow rays counted in `rays` / `shadow_rays` like the reference counts them but never
+                                          // traced: the light samples of hits that got no shadow record (k_shade, staged samples)
+    unsigned long long pad[5];
 };
+#define PT_N_COUNTERS 11                  // leading words of DCounters that are counters
 // Every workgroup adds its counts with a handful of atomics; on ONE set of words the ~4000 workgroups of a launch
 // serialise at the memory-side atomic rate (about 90 adds per microsecond per word), which was a 50-100 us floor per
 // launch.  The counters are therefore banked by workgroup index and summed on the host.
@@ -191,6 +194,7 @@ struct DBatch {
     // stay full instead of thinning out.
     int32_t n_seg, seg_cap;
     int32_t n_seg_out, seg_cap_out;
+    int32_t perm, perm_out;      // multipliers of the segment visiting order for n_seg and n_seg_out (pt_kernels.hip ChunkWalk; 1 = queue order)
     int32_t sort_shade;          // k_shade orders each chunk by shading class before shading it (PATHTRACE_HIP_NO_SORT=1: off)
     int32_t stage_shadow;        // k_shade stages a hit's light samples in LDS and gives hits whose samples cannot contribute no
                                  // shadow record (light_samples <= PT_STAGE_MAX_SAMPLES; PATHTRACE_HIP_NO_STAGE=1: off)

@@ -16,9 +16,9 @@
 //    and arrive through scalar loads into SGPRs; lanes that missed an enclosing box are masked off until
 //    the op where that subtree ends.  The per-lane short stack of partial results lives in LDS,
 //    [slot][lane] so that consecutive lanes hit consecutive banks.
-//  * Queues are segmented (pt_device.h): compaction = wave ballot + popcount prefix + a 4-entry LDS scan, then ONE
-//    atomicAdd per workgroup and queue on the output segment's counter.  Queue order is therefore not deterministic;
-//    per-path arithmetic does not depend on it, and k_accumulate adds a pixel's samples in sample order.
+//  * Queues are segmented (pt_device.h): compaction = one wave ballot + popcount prefix and ONE atomicAdd per wave on the
+//    output segment's counter (lane 0, the base broadcast through an SGPR; no barrier, no LDS).  Queue order is therefore
+//    not deterministic; per-path arithmetic does not depend on it, and k_accumulate adds a pixel's samples in sample order.
 //  * All streams are float4 / float2 planes indexed by queue position: each wave-level load or store is
 //    one fully coalesced 1 KiB / 512 B transaction.
 #include <hip/hip_runtime.h>
@@ -31,6 +31,15 @@
 #include "pt_fdiv.h"
 
 namespace ptd {
+
+// Per-scene build of the sweep (pt_context.cpp pt_spec_source; compiled with hiprtc at pt_create): PT_SPEC_HEADER names a
+// header that holds the scene's fast program as a compile-time table -- PT_SPEC_N ops, kSpecW[PT_SPEC_N][32] = the DOp
+// words -- so that world_hit_fast unrolls into straight-line code: op fetch, decode and dispatch fold away, every leaf
+// keeps only the body of its own kind and transform shape.  The arithmetic per ray is the generic sweep's, statement
+// for statement (same functions, same operands), so the result is the same bit for bit.
+#ifdef PT_SPEC_HEADER
+#include PT_SPEC_HEADER
+#endif
 
 #define PT_BLOCK 256
 #ifndef PT_SHADE_WAVES
@@ -654,12 +663,18 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
         cur_id[r] = -1;
         skipf[r] = lane_valid ? 0.0f : 1e9f;
     }
+#ifdef PT_SPEC_HEADER
+#define OPW(i) kSpecW[pc][(i)]
+#pragma unroll
+    for (int pc = 0; pc < PT_SPEC_N; ++pc) {
+#else
     const DOp *__restrict__ prog = S.ops + S.ops_fast_off;
     const int n_ops = S.n_ops_fast;
 #define OPW(i) ((i) < 16 ? w0[(i)] : w1[(i) - 16])
     for (int pc = 0; pc < n_ops; ++pc) {
         const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&prog[pc]);
         const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&prog[pc]) + 1);
+#endif
         const int kind = OPW(0), op_a = OPW(1), pat = OPW(2) & 15;
         const bool op_ieee = (OPW(2) & 16) != 0;    // this leaf's data are outside the unscaled division's precondition
         const int op_id_base = op_a * 8;
@@ -681,7 +696,13 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
                 skipf[r] = __int_as_float(max(__float_as_int(skipf[r]), (tmax <= tmin) ? __float_as_int(endf) : 0));
                 in_max = fminf(in_max, skipf[r] - pcf);
             }
+#ifdef PT_SPEC_HEADER
+            // straight-line code has no program counter to set: a subtree that no ray of the wave is inside is left by a
+            // forward branch when it is the rest of the program (the root's box), else its ops run masked (skipf)
+            if (op_a >= PT_SPEC_N && !__any(in_max <= 0.0f)) break;
+#else
             if (!__any(in_max <= 0.0f)) pc = op_a - 1;   // no ray of the wave is inside this subtree: jump to its end
+#endif
             continue;
         }
         const float m[12] = {OPF(0), OPF(1), OPF(2), OPF(3), OPF(4), OPF(5), OPF(6), OPF(7), OPF(8), OPF(9), OPF(10), OPF(11)};
@@ -1216,25 +1237,6 @@ DEVI v3 material_emitted(const DScene &S, const DMat &m, int id, const HitInfo &
 // ------------------------------------------------------------------------------------------------
 // workgroup helpers
 // ------------------------------------------------------------------------------------------------
-// exclusive offset of `pred` lanes within the workgroup and the workgroup total (two barriers)
-DEVI int block_compact(bool pred, int &total, int *sh4)
-{
-    const unsigned long long m = __ballot(pred);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int woff = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) sh4[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < PT_BLOCK / 64; w++) {
-        int c = sh4[w];
-        if (w < wave) off += c;
-        tot += c;
-    }
-    __syncthreads();
-    total = tot;
-    return off + woff;
-}
 // batch-local pixel -> film pixel (i, j)
 DEVI void batch_pixel(const DBatch &b, int pl, int &pi, int &pj)
 {
@@ -1252,6 +1254,30 @@ DEVI void batch_pixel(const DBatch &b, int pl, int &pi, int &pj)
     pi = x0 + (pl - py * w);
     pj = y0 + py;
 }
+// The order in which a persistent workgroup visits the 256-lane chunks of a segmented queue: linear index c = chunk * n_seg
+// + k (chunk-major: the live chunks of every segment are its first few), advanced by the grid stride without a division,
+// and k -> segment (k * mul) mod n_seg with mul ~ n_seg / golden ratio, coprime to n_seg (pt_context.cpp seg_perm).  The
+// multiplication scatters the segments a workgroup visits quasi-uniformly over the queue: in queue order a workgroup's
+// segments are an arithmetic progression of stride gridDim.x, which beats against the period of the image in slot space
+// (pixels per sample / segment size) -- at 2^18 pixels per batch every workgroup saw the SAME pixels of every sample, the
+// ones over the background idled while the ones over the box did all the work (k_shade 18.0 ms against 10.9).
+struct ChunkWalk {
+    int chunk, k, seg, g_chunks, g_k, d_seg, n_seg;
+    DEVI void init(int n_seg_, int mul)
+    {
+        n_seg = n_seg_;
+        g_chunks = (int)gridDim.x / n_seg; g_k = (int)gridDim.x - g_chunks * n_seg;
+        chunk = (int)blockIdx.x / n_seg; k = (int)blockIdx.x - chunk * n_seg;
+        seg = (int)(((uint32_t)k * (uint32_t)mul) % (uint32_t)n_seg);       // k, g_k, mul < n_seg < 2^16 (seg_perm): 32-bit products
+        d_seg = (int)(((uint32_t)g_k * (uint32_t)mul) % (uint32_t)n_seg);
+    }
+    DEVI void advance()
+    {
+        chunk += g_chunks; k += g_k; seg += d_seg;
+        if (seg >= n_seg) seg -= n_seg;
+        if (k >= n_seg) { k -= n_seg; chunk++; }
+    }
+};
 enum { C_SAMPLES = 0, C_RAYS, C_EXT, C_EXT_HITS, C_SHADOW, C_MISS, C_RR, C_EMIT, C_PDF, C_LIMIT, C_N };
 DEVI DCounters *counter_bank(DCounters *g) { return g + (blockIdx.x & (PT_COUNTER_BANKS - 1)); }
 DEVI void flush_counters(unsigned int *sh_ctr, DCounters *g)
@@ -1346,17 +1372,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // the live count of a chunk's segment is fetched one chunk ahead: the scalar load is in flight while the current chunk is
     // processed, and an empty chunk (the tail of a segment) costs a compare instead of a memory round trip
     // (chunk, seg) of the next chunk advance by the grid stride without a division per chunk
-    const int g_chunks = (int)gridDim.x / b.n_seg, g_segs = (int)gridDim.x - g_chunks * b.n_seg;
-    int nx_chunk = (int)blockIdx.x / b.n_seg, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg;
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx_seg] : 0;
+    ChunkWalk nx;
+    nx.init(b.n_seg, b.perm);
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx.seg] : 0;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
         // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
-        const int chunk = nx_chunk, seg = nx_seg;
+        const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
-        nx_chunk += g_chunks; nx_seg += g_segs;
-        if (nx_seg >= b.n_seg) { nx_seg -= b.n_seg; nx_chunk++; }
-        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx_seg];
+        nx.advance();
+        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx.seg];
         if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
             // zero the counters this bounce's shade will append to (segment g -> g >> 1; every output segment has an
             // even source).  The other path queue and the shadow queue are idle now: their last readers were the
@@ -1496,15 +1521,14 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     constexpr bool stage = STAGE;   // DBatch::stage_shadow picked the instantiation (launch_shade)
     float4 *const st_d = sh_stage + threadIdx.x;
     float2 *const st_e = reinterpret_cast<float2 *>(sh_stage + (size_t)L * PT_BLOCK) + threadIdx.x;
-    const int g_chunks = (int)gridDim.x / b.n_seg, g_segs = (int)gridDim.x - g_chunks * b.n_seg;   // see k_extend
-    int nx_chunk = (int)blockIdx.x / b.n_seg, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg;
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx_seg] : 0;   // one chunk ahead, see k_extend
+    ChunkWalk nx;   // see k_extend
+    nx.init(b.n_seg, b.perm);
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx.seg] : 0;   // one chunk ahead, see k_extend
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
-        const int chunk = nx_chunk, seg = nx_seg;
+        const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
-        nx_chunk += g_chunks; nx_seg += g_segs;
-        if (nx_seg >= b.n_seg) { nx_seg -= b.n_seg; nx_chunk++; }
-        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx_seg];
+        nx.advance();
+        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx.seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap;
@@ -1847,9 +1871,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         if (n_emit) atomicAdd(&cb->term_emitter, (unsigned long long)n_emit);
         if (n_pdf) atomicAdd(&cb->term_pdf, (unsigned long long)n_pdf);
         if (n_limit) atomicAdd(&cb->term_bounce_limit, (unsigned long long)n_limit);
-        if (n_dark) {   // the light_samples shadow rays of every hit without a record: counted like connect counts the traced ones
+        if (n_dark) {   // the light_samples shadow rays of every hit without a record: counted like the reference counts them
+            // (integrator.h:246-247) and, separately, as NOT traced (pt_counters::rays_traced leaves them out)
             atomicAdd(&cb->rays, (unsigned long long)n_dark * L);
             atomicAdd(&cb->shadow_rays, (unsigned long long)n_dark * L);
+            atomicAdd(&cb->shadow_untraced, (unsigned long long)n_dark * L);
         }
     }
 }
@@ -1904,15 +1930,14 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
     const CountDiv pick_pdf = count_div(S.n_lights);   // integrator.h:224
     const CountDiv n_samples = count_div(S.light_samples);
     unsigned long long n_rays = 0;
-    const int g_chunks = (int)gridDim.x / b.n_seg_out, g_segs = (int)gridDim.x - g_chunks * b.n_seg_out;   // see k_extend
-    int nx_chunk = (int)blockIdx.x / b.n_seg_out, nx_seg = (int)blockIdx.x - nx_chunk * b.n_seg_out;
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? sq.count[nx_seg] : 0;   // one chunk ahead, see k_extend
+    ChunkWalk nx;   // see k_extend
+    nx.init(b.n_seg_out, b.perm_out);
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? sq.count[nx.seg] : 0;   // one chunk ahead, see k_extend
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
-        const int chunk = nx_chunk, seg = nx_seg;
+        const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
-        nx_chunk += g_chunks; nx_seg += g_segs;
-        if (nx_seg >= b.n_seg_out) { nx_seg -= b.n_seg_out; nx_chunk++; }
-        if (c + (int)gridDim.x < total_chunks) n_ahead = sq.count[nx_seg];
+        nx.advance();
+        if (c + (int)gridDim.x < total_chunks) n_ahead = sq.count[nx.seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap_out;
@@ -2097,6 +2122,91 @@ void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, cons
 #undef PT_LAUNCH_TRACE
 }
 int launch_grid_max() { return persistent_grid(1ll << 40); }
+
+// ------------------------------------------------------------------------------------------------
+// tile-cost planner (pt_measure_tile_costs): after k_shade of every bounce, the World::hit queries this bounce PERFORMS are
+// added to the cost word of the image tile the path's pixel lies in -- one per live path (its extension ray, traced by
+// k_extend) and light_samples per shadow record k_shade wrote (the rays k_connect is about to trace; hits that got no
+// record cost no shadow rays).  One launch over the whole frame yields the traced-ray count of every tile; the render
+// kernels are untouched (this kernel only runs while a planner call has set the cost table).
+// ------------------------------------------------------------------------------------------------
+DEVI int tile_of_slot(const DBatch &b, int slot)
+{
+    const int pl = slot % b.npix;
+    if (b.n_tiles <= 1) return 0;
+    int lo = 0, hi = b.n_tiles - 1;   // last tile with pix0 <= pl (batch_pixel's search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.tiles[mid].pix0 <= pl) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int qi, int light_samples, unsigned long long *__restrict__ cost)
+{
+    const DQueue q = st.q[qi];
+    const int cps = b.seg_cap / PT_BLOCK, total_chunks = b.n_seg * cps;
+    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {           // the paths this bounce extended
+        const int seg = c / cps, i = (c - seg * cps) * PT_BLOCK + (int)threadIdx.x;
+        if (i >= q.count[seg]) continue;
+        const int slot = __float_as_int(q.r0[(long long)seg * b.seg_cap + i].w);
+        atomicAdd(cost + tile_of_slot(b, slot), 1ull);
+    }
+    const int cps_o = b.seg_cap_out / PT_BLOCK, total_o = b.n_seg_out * cps_o;
+    for (int c = blockIdx.x; c < total_o; c += gridDim.x) {                // the shadow records this bounce wrote
+        const int seg = c / cps_o, i = (c - seg * cps_o) * PT_BLOCK + (int)threadIdx.x;
+        if (i >= st.sq.count[seg]) continue;
+        const int slot = __float_as_int(st.sq.p0[(long long)seg * b.seg_cap_out + i].w) & 0x7fffffff;
+        atomicAdd(cost + tile_of_slot(b, slot), (unsigned long long)light_samples);
+    }
+}
+void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, unsigned long long *cost, hipStream_t s)
+{
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+    hipLaunchKernelGGL(k_tally, grid, block, 0, s, st, b, qi, S.light_samples, cost);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU exchange (pt_multi.cpp): a device sends only the pixels of the tiles it owns.  rects = n x (x0, y0, x1, y1),
+// pix0[k] = packed index of rect k's first pixel (pix0[n] = total), row-major inside a rect.
+// ------------------------------------------------------------------------------------------------
+DEVI long long packed_to_film(const int4 *__restrict__ rects, const int *__restrict__ pix0, int n, int width, int p)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pix0[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int4 r = rects[lo];
+    const int w = r.z - r.x, l = p - pix0[lo], py = l / w;
+    return (long long)(r.y + py) * width + (r.x + (l - py * w));
+}
+__global__ __launch_bounds__(PT_BLOCK) void k_pack_tiles(float4 *__restrict__ packed, const float4 *__restrict__ fb, const int4 *__restrict__ rects,
+                                                         const int *__restrict__ pix0, int n, int width, int total)
+{
+    for (int p = blockIdx.x * PT_BLOCK + threadIdx.x; p < total; p += gridDim.x * PT_BLOCK) packed[p] = fb[packed_to_film(rects, pix0, n, width, p)];
+}
+// dst += packed over the same rect list: disjoint ownership, so every film pixel receives one non-zero term in all
+__global__ __launch_bounds__(PT_BLOCK) void k_unpack_add_tiles(float4 *__restrict__ fb, const float4 *__restrict__ packed, const int4 *__restrict__ rects,
+                                                               const int *__restrict__ pix0, int n, int width, int total)
+{
+    for (int p = blockIdx.x * PT_BLOCK + threadIdx.x; p < total; p += gridDim.x * PT_BLOCK) {
+        const long long f = packed_to_film(rects, pix0, n, width, p);
+        const float4 a = fb[f], v = packed[p];
+        fb[f] = make_float4(a.x + v.x, a.y + v.y, a.z + v.z, a.w + v.w);
+    }
+}
+void launch_pack_tiles(void *packed, const void *fb, const void *rects, const void *pix0, int n, int width, int total, hipStream_t s)
+{
+    if (total < 1) return;
+    const int blocks = (int)((total + PT_BLOCK - 1) / PT_BLOCK < 4096 ? (total + PT_BLOCK - 1) / PT_BLOCK : 4096);
+    hipLaunchKernelGGL(k_pack_tiles, dim3(blocks), dim3(PT_BLOCK), 0, s, (float4 *)packed, (const float4 *)fb, (const int4 *)rects, (const int *)pix0, n, width, total);
+}
+void launch_unpack_add_tiles(void *fb, const void *packed, const void *rects, const void *pix0, int n, int width, int total, hipStream_t s)
+{
+    if (total < 1) return;
+    const int blocks = (int)((total + PT_BLOCK - 1) / PT_BLOCK < 4096 ? (total + PT_BLOCK - 1) / PT_BLOCK : 4096);
+    hipLaunchKernelGGL(k_unpack_add_tiles, dim3(blocks), dim3(PT_BLOCK), 0, s, (float4 *)fb, (const float4 *)packed, (const int4 *)rects, (const int *)pix0, n, width, total);
+}
 // multi-GPU reduce on the root device (pt_multi.cpp): dst += src over RGBA framebuffers whose tiles are disjoint
 __global__ __launch_bounds__(PT_BLOCK) void k_add_fb(float4 *__restrict__ dst, const float4 *__restrict__ src, long long n)
 {

@@ -965,10 +965,11 @@ public:
 };
 
 // render_type "hip_wavefront": start_render enqueues the whole image on the GPU(s) and returns; sync_progress polls.
-// Every visible device takes part (pt_multi: tiles of block_width x block_height in NaiveSpiral order, cost-balanced
-// ownership, one sum into the first device at the end) -- the counterpart of Tiled's config.threads workers over one tile
-// queue (renderer.h:553-603).  PATHTRACE_HIP_DEVICES="0,1,.." picks the devices; an ordinal may repeat ("0,0": two
-// contexts on one GPU, the rehearsal of the multi-GPU path on a one-GPU box).  One device: a single context, no tiles.
+// Default: ONE context on the current device.  PATHTRACE_HIP_DEVICES="0,1,.." lists the devices that take part (pt_multi:
+// tiles of block_width x block_height in NaiveSpiral order, cost-balanced ownership, one sum into the first device at the
+// end) -- the counterpart of Tiled's config.threads workers over one tile queue (renderer.h:553-603); "all" = every
+// visible device; an ordinal may repeat ("0,0": two contexts on one GPU, the rehearsal of the multi-GPU path on a one-GPU
+// box).  The in-process multi-device form has only been rehearsed on one GPU so far, hence it is opt-in.
 class HipWavefront : public Renderer {
 public:
     HipWavefront(const pth_config &cfg, const pt_scene_desc *scene)
@@ -979,7 +980,10 @@ public:
         pc.russian_roulette = cfg.russian_roulette; pc.only_direct_illumination = cfg.only_direct_illumination;
         pc.normal_offset = cfg.normal_offset; pc.seed = 0; pc.device = -1; pc.max_paths_in_flight = 0;
         std::vector<int32_t> devices;
-        if (const char *e = getenv("PATHTRACE_HIP_DEVICES")) {
+        const char *e = getenv("PATHTRACE_HIP_DEVICES");
+        if (e && !strcmp(e, "all")) {
+            for (int d = 0; d < pt_device_count(); d++) devices.push_back(d);
+        } else if (e) {
             for (const char *p = e; *p;) {
                 char *end = nullptr;
                 long v = strtol(p, &end, 10);
@@ -987,8 +991,6 @@ public:
                 devices.push_back((int32_t)v);
                 p = (*end == ',') ? end + 1 : end;
             }
-        } else {
-            for (int d = 0; d < pt_device_count(); d++) devices.push_back(d);
         }
         if (devices.size() > 1) {
             multi = pt_multi_create(scene, &pc, (int32_t)devices.size(), devices.data(), std::max(cfg.block_width, 1), std::max(cfg.block_height, 1));
@@ -1041,7 +1043,15 @@ public:
         if (multi ? pt_multi_get_counters(multi, &c) : pt_get_counters(ctx, &c)) throw JsonError(pt_last_error());
         if (multi ? pt_multi_read_framebuffer(multi, framebuffer.data()) : pt_read_framebuffer(ctx, framebuffer.data())) throw JsonError(pt_last_error());
         printf("\ntime taken to compute %g\n", dt);
-        if (multi) printf("rendered on %d devices\n", pt_multi_device_count(multi));
+        if (multi) {
+            printf("rendered on %d devices\n", pt_multi_device_count(multi));
+            for (int d = 0; d < pt_multi_device_count(multi); d++) {   // the reference prints one bounce count per worker thread
+                pt_counters dc{};
+                if (pt_multi_get_device_counters(multi, d, &dc)) throw JsonError(pt_last_error());
+                printf("  device slot %d: %llu camera rays, %llu rays (%llu traced)\n", d, (unsigned long long)dc.camera_samples,
+                       (unsigned long long)dc.rays, (unsigned long long)dc.rays_traced);
+            }
+        }
         printf("computed %llu camera rays in %gs, at %g rays per second\n", (unsigned long long)c.camera_samples, dt, c.camera_samples / dt);
         printf("computed %llu rays, at %g rays per second\n", (unsigned long long)c.rays, c.rays / dt);
         if (pth_write_ppm(config.ppm_output_path, framebuffer.data(), config.width, config.height, config.samples, config.exposure))

@@ -36,10 +36,24 @@ def balanced_owners(costs: Sequence[int], world: int) -> List[int]:
     return owner
 
 
+def snake_owners(costs: Sequence[int], world: int) -> List[int]:
+    """Owner rank of every tile: tiles sorted by cost (ties by spiral index) are dealt out in snake order -- ranks
+    0 .. world-1, then world-1 .. 0, and so on -- so that every rank receives one tile of every cost stratum: equal tile
+    counts (within one) and the same MIX of cheap and costly tiles, not only equal sums."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    order = sorted(range(len(costs)), key=lambda k: (-int(costs[k]), k))
+    owner = [0] * len(costs)
+    for i, k in enumerate(order):
+        rnd, pos = divmod(i, world)
+        owner[k] = pos if rnd % 2 == 0 else world - 1 - pos
+    return owner
+
+
 def tiles_for_rank(width: int, height: int, block_w: int, block_h: int, rank: int, world: int,
-                   costs: Optional[Sequence[int]] = None) -> List[Tuple[int, int, int, int]]:
+                   costs: Optional[Sequence[int]] = None, strategy: str = "lpt") -> List[Tuple[int, int, int, int]]:
     """Tile rects (x0, y0, x1, y1) owned by `rank`, in NaiveSpiral order.  Without costs: tile k -> rank k mod world;
-    with one cost per spiral tile: the cost-balanced map of `balanced_owners`."""
+    with one cost per spiral tile: the cost-balanced map of `balanced_owners` ("lpt") or `snake_owners` ("snake")."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world of {world}")
     tiles = spiral_tiles(width, height, block_w, block_h)
@@ -47,25 +61,18 @@ def tiles_for_rank(width: int, height: int, block_w: int, block_h: int, rank: in
         return tiles[rank::world]
     if len(costs) != len(tiles):
         raise ValueError(f"{len(costs)} costs for {len(tiles)} tiles")
-    owner = balanced_owners(costs, world)
+    owner = snake_owners(costs, world) if strategy == "snake" else balanced_owners(costs, world)
     return [t for t, o in zip(tiles, owner) if o == rank]
 
 
 def measure_tile_costs(renderer, tiles) -> List[int]:
-    """Work per tile in ray-equivalents: World::hit queries of one sample per pixel plus one unit per camera sample (ray
-    generation + framebuffer accumulation).  `renderer` is a pathtrace_amd.Renderer; its framebuffer and counters are
-    cleared afterwards.  Deterministic (the RNG is keyed by pixel and sample), so all ranks agree."""
-    costs = []
-    renderer.clear()
-    prev = renderer.counters()
-    for t in tiles:
-        renderer.render_tiles_async([t], 0, 1)
-        renderer.wait()
-        c = renderer.counters()
-        costs.append((c["rays"] - prev["rays"]) + (c["camera_samples"] - prev["camera_samples"]))
-        prev = c
-    renderer.clear()
-    return costs
+    """Work per tile in ray-equivalents: World::hit queries performed for one sample per pixel (extension rays + the shadow
+    rays of the hits that get a shadow record) plus one unit per camera sample (ray generation + framebuffer accumulation).  `renderer` is a pathtrace_amd.Renderer; its framebuffer and counters are
+    cleared afterwards.  Deterministic (the RNG is keyed by pixel and sample), so all ranks agree.  One pass over all
+    tiles (pt_measure_tile_costs: a tally kernel attributes every bounce's rays to the tile of the path's pixel), not
+    one render and one blocking counter read per tile."""
+    rays = renderer.measure_tile_costs(tiles, 1)
+    return [r + (x1 - x0) * (y1 - y0) for r, (x0, y0, x1, y1) in zip(rays, tiles)]
 
 
 def reduce_framebuffer(fb, dst: int = 0):

@@ -33,6 +33,19 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank():
         assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
     for d in (one, two):
         assert d["roofline"]["bound"] in ("hbm", "valu") and d["value"] > 0 and d["steps"] == 4
+        # value = rays the device traced; the reference's count for the same image is reported beside it
+        assert d["value"] <= d["value_reference_equivalent"] and d["config"]["rays_traced"] <= d["config"]["rays"]
+        ser = d["roofline"]["serialised"]
+        # the roofline block is reproducible from the line alone: one lane, so the kernels' event times do not overlap
+        assert ser["lanes"] == 1 and ser["kernel_ms_sum"] <= ser["wall_ms"] * 1.02
+        dom = d["roofline"]["kernel"][2:]
+        assert abs(d["roofline"]["achieved"] - ser["kernels"][dom]["model_bytes"] / ser["kernels"][dom]["ms"] / 1e6) <= 0.01 * d["roofline"]["achieved"] + 0.1
+    # N = 1 carries the one-GPU strong-scaling proxy: every rank of 2 / 4 / 8 renders the same total work
+    px = one["scaling_proxy"]
+    assert [e["n"] for e in px["by_n"]] == [2, 4, 8]
+    for e in px["by_n"]:
+        assert e["rays_all_ranks"] == one["config"]["rays"] and min(e["batches_per_rank"]) >= 2 and e["predicted_efficiency"] > 0
+    assert two["scaling_proxy"] is None
 
 
 def test_rccl_world_size_one_reduce_of_the_library_framebuffer():

@@ -43,6 +43,12 @@ def test_contexts_on_one_gpu_reassemble_the_single_context_image(scene, n_ctx, m
         assert done and samples == w * h * spp and rays == ref_c["rays"]
         fb2 = m.framebuffer()                       # reading twice does not add twice
         assert np.array_equal(bits(fb2), bits(ref))
+        # the exchange moves only the pixels the peers (every context but the first) own, 16 bytes each
+        tiles = pt.spiral_tiles(w, h, 64, 64)
+        peer_px = sum((t[2] - t[0]) * (t[3] - t[1]) for t, o in zip(tiles, owners) if o != 0)
+        assert m.exchange_bytes() == 16 * peer_px < 16 * w * h
+        per_dev = [m.device_counters(i) for i in range(n_ctx)]
+        assert all(sum(d[k] for d in per_dev) == v for k, v in ref_c.items()) and all(d["rays"] > 0 for d in per_dev)
         m.clear()
         m.render_async(0, 1)
         assert m.counters()["camera_samples"] == w * h

@@ -109,7 +109,11 @@ def test_hits_without_a_shadow_record_change_nothing(oracle, scene, monkeypatch)
     staged, c0 = gpu_render(scene, w, h, spp, seed=9)
     monkeypatch.setenv("PATHTRACE_HIP_NO_STAGE", "1")
     plain, c1 = gpu_render(scene, w, h, spp, seed=9)
-    assert np.array_equal(bits(staged), bits(plain)) and c0 == c1
+    traced = ("rays_traced", "shadow_rays_traced")
+    assert np.array_equal(bits(staged), bits(plain)) and {k: v for k, v in c0.items() if k not in traced} == {k: v for k, v in c1.items() if k not in traced}
+    # the reference's count is the same either way; what was traced differs: every ray without staging, fewer with it
+    assert c1["rays_traced"] == c1["rays"] and c1["shadow_rays_traced"] == c1["shadow_rays"]
+    assert c0["rays"] - c0["rays_traced"] == c0["shadow_rays"] - c0["shadow_rays_traced"] > 0 and c0["shadow_rays_traced"] % 4 == 0
     assert_bit_identical(staged, ref, scene)
     assert_counters(c0, oc, scene)
 
@@ -172,13 +176,28 @@ def test_cost_balanced_tile_ownership(oracle):
     r = pt.Renderer(sc)
     tiles = pt.spiral_tiles(w, h, tile, tile)
     costs = measure_tile_costs(r, tiles)
+    assert r.counters()["rays"] == 0 and not r.framebuffer().any()      # measuring leaves no trace
+    # a tile's cost = the rays the device traces for it (one sample per pixel) + one unit per pixel: the tile rendered alone
+    # says the same, and the extension rays among them are the oracle's
     osc = oracle.Scene.from_json(scene_path(scene))
     cfg = oracle_cfg(oracle, w, h, 1)
     scratch = np.zeros((h, w, 3), np.float32)
     for k in (0, 1, len(tiles) // 2, len(tiles) - 1):
+        r.clear()
+        r.render_tiles_async([tiles[k]], 0, 1)
+        ck = r.counters()
         _, oc = osc.render_stream(cfg, seed=0, rect=tiles[k], threads=2, fb=scratch)
-        assert costs[k] == oc["rays"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1])
-    assert r.counters()["rays"] == 0 and not r.framebuffer().any()      # measuring leaves no trace
+        assert ck["rays"] == oc["rays"] and ck["extension_rays"] == oc["ext_rays"]
+        assert costs[k] == ck["rays_traced"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1])
+    r.clear()
+    # the same counts when the slot budget cuts the tiles into bands and the pass into several batch groups, and for 2 spp
+    r_small = pt.Renderer(sc, max_paths_in_flight=5000)
+    assert measure_tile_costs(r_small, tiles) == costs
+    two = r_small.measure_tile_costs(tiles[:5], 2)
+    r_small.close()
+    r.render_tiles_async([tiles[1]], 0, 2)
+    assert two[1] == r.counters()["rays_traced"]
+    r.clear()
     per_rank = [tiles_for_rank(w, h, tile, tile, k, world, costs) for k in range(world)]
     assert sorted(t for tr in per_rank for t in tr) == sorted(tiles)
     loads = [sum(costs[tiles.index(t)] for t in tr) for tr in per_rank]

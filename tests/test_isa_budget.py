@@ -13,13 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 VALU = ("fp2", "fp2s", "v4", "pk", "trans")
-# kernel -> (min occupancy, max static VALU instructions, max basic block, max scalar instructions, max spilled VGPRs)
+# kernel -> (min occupancy, max static VALU instructions, max basic block, max scalar instructions, max spilled VGPRs,
+#            max spilled SGPRs: a spilled SGPR is a v_writelane / v_readlane pair through a VGPR the kernel then cannot use)
 BUDGET = {
-    "void ptd::k_extend<false, false>": (7, 1110, 220, 500, 0),
-    "void ptd::k_connect<2, false, false, false>": (6, 2800, 370, 750, 0),
+    "void ptd::k_extend<false, false>": (7, 1110, 220, 530, 0, 12),
+    "void ptd::k_connect<2, false, false, false>": (6, 2800, 370, 790, 0, 45),
     # a few loop-invariant lane values of the prologue live in scratch: one reload each per 256-path chunk
-    "void ptd::k_shade<false, 1, true>": (6, 3000, 330, 1300, 4),
-    "ptd::k_generate": (8, 400, 140, 200, 0),
+    "void ptd::k_shade<false, 1, true>": (6, 3000, 330, 1350, 4, 108),
+    "ptd::k_generate": (8, 400, 140, 200, 0, 0),
 }
 
 
@@ -32,10 +33,11 @@ def kernels():
 @pytest.mark.parametrize("name", sorted(BUDGET))
 def test_headline_kernel_stays_inside_its_budget(kernels, name):
     k = kernels[name]
-    occ, valu_max, block_max, salu_max, spill_max = BUDGET[name]
+    occ, valu_max, block_max, salu_max, spill_max, sgpr_spill_max = BUDGET[name]
     valu = sum(k["total"].get(c, 0) for c in VALU)
     biggest = max(sum(v for c, v in d.items() if c != "div*") for _, d in k["blocks"])
     assert k["vgpr_spills"] <= spill_max and k["scratch"] <= 8 * spill_max, (k["vgpr_spills"], k["scratch"])
+    assert k["sgpr_spills"] <= sgpr_spill_max, k["sgpr_spills"]
     assert k["occupancy"] >= occ, (k["occupancy"], k["vgpr"])
     assert valu <= valu_max, valu
     assert biggest <= block_max, biggest
