@@ -1435,6 +1435,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
 // hit comes from the per-face table (pt_device.h PT_FACE_F4), computed on the host with the same float operations; what
 // is left per hit is the local hit point, rec.p = transform * p_local and the facing test.
 struct ShadeHit { v3 p, n, nu, ou, ov, pl; int mat; };
+template <int P> struct PlaneTag { static constexpr int value = P; };   // a rect's alignment as a compile-time value (k_shade's light samples)
 DEVI ShadeHit shade_hit(const DScene &S, v3 A, v3 B, float t, int id)
 {
     const DInst &in = S.insts[id >> 3];
@@ -1476,8 +1477,11 @@ DEVI float cosine_pdf_of(float cosine)
         // a float denormal, pay for the IEEE double division.
         const double q = (double)cosine * 0.31830988618379067154;
         const unsigned lo = (unsigned)__double2loint(q) & 0x1fffffffu;
-        if (lo - 0x0ffffff0u <= 0x20u || !(cosine > 1e-30f)) return (float)((double)cosine / PT_PI_D);
-        return (float)q;
+        float r = (float)q;
+        // one call in 10^7: a real branch (the empty asm keeps hipcc from computing the f64 division -- eleven f64 instructions
+        // -- on every call and selecting, which it did)
+        if (__builtin_expect(lo - 0x0ffffff0u <= 0x20u || !(cosine > 1e-30f), 0)) { asm volatile("; cosine_pdf: exact division"); r = (float)((double)cosine / PT_PI_D); }
+        return r;
     }
     return 0.0f;
 }
@@ -1757,8 +1761,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             //  * its t = (y - o.y) / d.y divides a float by itself -- d.y = y - o.y is the same subtraction -- which is
             //    exactly 1 for a finite non-zero value and NaN otherwise (0 / 0);
             //  * dot(v, normal) has two exact-zero terms: |dot| = |v.y| for the finite v here.
-            // The rect's fields may be per-lane values (the light a lane drew) or wave-uniform; `plane` is wave-uniform.
-            auto rect_light_sample = [&](const uint32_t k, const uint32_t kb, v3 tl, float x0, float z0, float x1, float z1, float y, int plane) {
+            // The rect's fields may be per-lane values (the light a lane drew) or wave-uniform; the alignment is wave-uniform and
+            // a compile-time constant here (plane_c: std::integral_constant-like tag): as a run-time value its shuffles were
+            // eight scalar branches with register moves per sample.
+            auto rect_light_sample = [&](auto plane_c, const uint32_t k, const uint32_t kb, v3 tl, float x0, float z0, float x1, float z1, float y) {
+                constexpr int plane = decltype(plane_c)::value;
                 const v3 ol = V(tl.x + hp.x, tl.y + hp.y, tl.z + hp.z);
                 const v3 os = shuffle(ol, plane);
                 const float area = (x1 - x0) * (z1 - z0);
@@ -1798,8 +1805,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const bool tr = lin.ident && wave_finite;
                 if (tr && lpr.type == 0) {
                     const DRect &lq = lpr.r[0];
-                    for (uint32_t k = 0; k < L; k++)
-                        rect_light_sample(k, base + NV + k * (3u + NV), V(lin.inv[3], lin.inv[7], lin.inv[11]), lq.x0, lq.z0, lq.x1, lq.z1, lq.y, lq.plane);
+                    const v3 tl = V(lin.inv[3], lin.inv[7], lin.inv[11]);
+                    // one loop per alignment (wave-uniform branch); the empty asm keeps the three bodies apart
+                    if (lq.plane == 0) { asm volatile("; rect light xy"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<0>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
+                    else if (lq.plane == 2) { asm volatile("; rect light yz"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<2>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
+                    else { asm volatile("; rect light xz"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<1>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
                 } else {
                     for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, lpr, tr);
                 }
@@ -1816,9 +1826,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     const bool second = (int)(rnd(k0, k1, kb + 0) * 2.0) != 0;            // world.h:31-35
                     if (both_tr) {
                         const DRect &qa = pa.r[0], &qb = pb.r[0];
-                        rect_light_sample(k, kb, V(second ? ib.inv[3] : ia.inv[3], second ? ib.inv[7] : ia.inv[7], second ? ib.inv[11] : ia.inv[11]),
-                                          second ? qb.x0 : qa.x0, second ? qb.z0 : qa.z0, second ? qb.x1 : qa.x1, second ? qb.z1 : qa.z1,
-                                          second ? qb.y : qa.y, qa.plane);
+                        const v3 tl = V(second ? ib.inv[3] : ia.inv[3], second ? ib.inv[7] : ia.inv[7], second ? ib.inv[11] : ia.inv[11]);
+                        const float x0 = second ? qb.x0 : qa.x0, z0 = second ? qb.z0 : qa.z0, x1 = second ? qb.x1 : qa.x1, z1 = second ? qb.z1 : qa.z1;
+                        const float y = second ? qb.y : qa.y;
+                        if (qa.plane == 0) { asm volatile("; rect lights xy"); rect_light_sample(PlaneTag<0>{}, k, kb, tl, x0, z0, x1, z1, y); }
+                        else if (qa.plane == 2) { asm volatile("; rect lights yz"); rect_light_sample(PlaneTag<2>{}, k, kb, tl, x0, z0, x1, z1, y); }
+                        else { asm volatile("; rect lights xz"); rect_light_sample(PlaneTag<1>{}, k, kb, tl, x0, z0, x1, z1, y); }
                         continue;
                     }
                     DInst lin;
