@@ -163,6 +163,7 @@ def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
     total = spp_step * steps
     spp_launch = launch_plan(w * h, total)
     r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=min(w * h * spp_launch, MAX_BATCH_PATHS))
+    spec = r.spec_wait()   # the scene's own build of the traversal kernels (hiprtc at pt_create); -1 = generic kernels
 
     def run(s0, s1):
         s = s0
@@ -190,7 +191,7 @@ def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
             "value": round(c["rays_traced"] / dt / 1e6, 2), "value_reference_equivalent": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
             "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4),
             "traced_share": round(c["rays_traced"] / max(c["rays"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
-            "dominant_kernel": "k_" + dom,
+            "dominant_kernel": "k_" + dom, "sweep": "per-scene build" if spec == 1 else "generic",
             "kernel_ms_serialised_one_launch": {k: round(v["ms"], 3) for k, v in kt.items()}}
 
 
@@ -264,6 +265,9 @@ def main():
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
     spp_launch = launch_plan(my_pixels, total_spp)
     r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=min(my_pixels * spp_launch, MAX_BATCH_PATHS))
+    # pt_create started the per-scene build of the traversal kernels (hiprtc, ~2 s, like the scene upload outside the timed
+    # region); wait for it so that every timed launch runs the same kernels.  -1: not available, the generic kernels run.
+    spec_state = r.spec_wait()
     # render straight into a torch tensor so that the final reduce needs no copy
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
@@ -389,6 +393,7 @@ def main():
                 plans = [launch_plan(px, total_spp) for px in pix]
                 rp = pt.Renderer(scene, device=local_rank, seed=0,
                                  max_paths_in_flight=min(max(px * sl for px, sl in zip(pix, plans)), MAX_BATCH_PATHS))
+                rp.spec_wait()
                 render_range(rp, lists[0], 0, plans[0], plans[0])   # warm-up: one launch
                 rp.wait()
                 times, rr_, cs_, tr_, full_ = [], [], [], [], []
@@ -489,6 +494,7 @@ def main():
                        "framebuffer_sum": fb_sum,
                        "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce"),
                        "partition_setup_ms": round(setup_ms, 1),
+                       "sweep": "per-scene build of k_extend (hiprtc at pt_create), generic k_connect" if spec_state == 1 else "generic kernels",
                        "knobs": knobs},
             "roofline": roofline,
             "scaling_proxy": proxy,

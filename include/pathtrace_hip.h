@@ -192,6 +192,14 @@ int pt_measure_tile_costs(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, in
  * (PT_SPEC_HEADER).  Host only (no device needed).  Returns the text length; buf receives it when cap > length.
  * < 0: the scene has no program to specialise (the generic kernels run). */
 int pt_spec_header(const pt_scene_desc *scene, char *buf, size_t cap);
+/* pt_create compiles the traversal kernels once more for the scene at hand (hiprtc; env PATHTRACE_HIP_SPEC = async
+ * [default: on a thread of its own, used when ready] | sync | off).  pt_spec_status: 1 = in use, 0 = still building (the
+ * generic kernels run meanwhile), -1 = not available (pt_last_error says why; the generic kernels run).  pt_spec_wait
+ * blocks until the build has ended and returns the same.  The image is the same bit for bit either way. */
+int pt_spec_status(pt_ctx *ctx);
+int pt_spec_wait(pt_ctx *ctx);
+/* host-only check: compile the scene's module for gfx950 without a device; returns its code size, < 0 on failure */
+long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_samples);
 int pt_set_profiling(pt_ctx *ctx, int enabled);
 int pt_get_kernel_times(pt_ctx *ctx, pt_kernel_times *out);
 /* debug / parity: radiance of every camera sample of the LAST batch rendered (de_nan not applied):

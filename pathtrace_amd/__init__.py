@@ -101,7 +101,7 @@ class HostConfig(C.Structure):
 # every symbol include/pathtrace_hip.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
-           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header",
+           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header", "pt_spec_status", "pt_spec_wait", "pt_spec_build_check",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_render_async", "pt_multi_poll", "pt_multi_wait",
            "pt_multi_read_framebuffer", "pt_multi_snapshot_framebuffer", "pt_multi_get_counters", "pt_multi_clear",
@@ -144,6 +144,10 @@ def lib():
     L.pt_set_lanes.argtypes = [vp, C.c_int32]
     L.pt_measure_tile_costs.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint64)]
     L.pt_spec_header.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.c_size_t]
+    L.pt_spec_status.argtypes = [vp]
+    L.pt_spec_wait.argtypes = [vp]
+    L.pt_spec_build_check.argtypes = [C.POINTER(SceneDesc), C.c_int32]
+    L.pt_spec_build_check.restype = C.c_long
     L.pt_multi_get_device_counters.argtypes = [vp, C.c_int32, C.POINTER(Counters)]
     L.pt_multi_exchange_bytes.argtypes = [vp]
     L.pt_multi_exchange_bytes.restype = C.c_uint64
@@ -266,6 +270,14 @@ def spec_header(scene: "Scene") -> str:
     return buf.value.decode()
 
 
+def spec_build_check(scene: "Scene", light_samples: int = 4) -> int:
+    """Compile the scene's own traversal kernels for gfx950 (hiprtc, host only); returns the code object size."""
+    n = lib().pt_spec_build_check(C.byref(scene.desc), light_samples)
+    if n < 0:
+        raise PathtraceError(f"pt_spec_build_check: {last_error()}")
+    return n
+
+
 def load_config(path: str = None, text: str = None) -> HostConfig:
     hc = HostConfig()
     if text is not None:
@@ -360,6 +372,14 @@ class Renderer:
         out = (C.c_uint64 * len(rects))()
         _check(lib().pt_measure_tile_costs(self._h, len(rects), arr, spp, out), "pt_measure_tile_costs")
         return [int(v) for v in out]
+
+    def spec_status(self) -> int:
+        """Per-scene build of the sweep: 1 in use, 0 still building, -1 not available (the generic kernels run)."""
+        return lib().pt_spec_status(self._h)
+
+    def spec_wait(self) -> int:
+        """Block until the per-scene build has ended; 1 = the context launches the scene's own kernels, -1 = generic."""
+        return lib().pt_spec_wait(self._h)
 
     def set_profiling(self, on: bool):
         _check(lib().pt_set_profiling(self._h, int(on)), "pt_set_profiling")

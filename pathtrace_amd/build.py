@@ -16,12 +16,14 @@ LIB = os.path.join(LIB_DIR, "libpathtrace_hip.so")
 SOURCES = [
     os.path.join(CSRC, "device", "pt_kernels.hip"),
     os.path.join(CSRC, "device", "pt_context.cpp"),
+    os.path.join(CSRC, "device", "pt_spec.cpp"),
     os.path.join(CSRC, "device", "pt_multi.cpp"),
     os.path.join(CSRC, "host", "pt_host.cpp"),
 ]
 HEADERS = [
     os.path.join(CSRC, "device", "pt_device.h"),
     os.path.join(CSRC, "device", "pt_fdiv.h"),
+    os.path.join(CSRC, "device", "pt_spec.h"),
     os.path.join(CSRC, "host", "json_min.h"),
     os.path.join(HERE, "..", "include", "pathtrace_hip.h"),
 ]
@@ -30,6 +32,23 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # aligned pairs -- every packed op then costs two s_mov on the (single per CU) scalar unit and extra VGPRs.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-ldl"]
+
+
+def embed_sources() -> None:
+    """The device sources as string literals for pt_spec.cpp (the per-scene hiprtc build compiles them again at pt_create):
+    generated files, never edited and not tracked."""
+    for name, src in (("kernels", "pt_kernels.hip"), ("device", "pt_device.h"), ("fdiv", "pt_fdiv.h")):
+        text = open(os.path.join(CSRC, "device", src)).read()
+        assert ")PTSRC\"" not in text
+        # a string literal is limited to 64 KiB by some compilers: emit adjacent raw literals of at most 16 KiB
+        parts, step = [], 16000
+        for i in range(0, len(text), step):
+            parts.append('R"PTSRC(' + text[i:i + step] + ')PTSRC"')
+        out = os.path.join(CSRC, "device", f"pt_kernel_src_{name}.inc")
+        new = "\n".join(parts) + "\n"
+        if not os.path.exists(out) or open(out).read() != new:
+            with open(out, "w") as f:
+                f.write(new)
 
 
 def needs_build() -> bool:
@@ -44,6 +63,7 @@ def build(force: bool = False, verbose: bool = False, defs=(), out: str = None) 
     if out is None and not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
+    embed_sources()
     target = os.path.join(LIB_DIR, out) if out else LIB
     cmd = [HIPCC] + FLAGS + list(defs) + SOURCES + ["-o", target]
     if verbose:

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -16,15 +17,16 @@
 
 #include "../../../include/pathtrace_hip.h"
 #include "pt_device.h"
+#include "pt_spec.h"
 
 namespace ptd {
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
-void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
+void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s, SpecJob *spec);
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s);
-void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s);
+void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s, SpecJob *spec);
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
 void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
-                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s);
+                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s, SpecJob *spec);
 void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, unsigned long long *cost, hipStream_t s);
 int launch_grid_max();
 }  // namespace ptd
@@ -112,6 +114,8 @@ struct pt_ctx {
     size_t tally_cap = 0;
     std::vector<int> band_rect;      // rect index of every band of the current pt_render_tiles_async call
     std::vector<size_t> band_table;  // its index in the tile table
+    // the scene's own build of the sweep (pt_spec.cpp): null = off / not applicable; launches use it once spec_poll says 1
+    SpecJob *spec = nullptr;
     // profiling
     bool profiling = false;
     std::vector<TimedLaunch> timed;
@@ -777,6 +781,17 @@ extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config
     if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) { set_err("pt_create: event"); return fail(); }
     if (build_scene(c, scene)) return fail();
     if (alloc_streams(c)) return fail();
+    {   // the per-scene build of the sweep: PATHTRACE_HIP_SPEC = async (default: built on a thread of its own, used when ready),
+        // sync (built before pt_create returns), off.  Scenes without a fast program keep the generic kernels.
+        const char *mode = getenv("PATHTRACE_HIP_SPEC");
+        const bool off = mode && !strcmp(mode, "off");
+        std::string table;
+        if (!off && !c->S.walk && spec_header_text(scene, table) > 0) {
+            const int L = c->cfg.light_samples;
+            c->spec = spec_start(table, c->S.geom_all != 0, c->S.textured != 0, (L % 2 == 0) ? 2 : 1, c->device, mode && !strcmp(mode, "sync"));
+        }
+        g_err.clear();   // spec_header_text leaves a message for scenes it does not serve: not an error of pt_create
+    }
     return c;
 }
 
@@ -790,6 +805,7 @@ extern "C" void pt_destroy(pt_ctx *c)
         if (c->lanes[l].acc_done) (void)hipEventDestroy(c->lanes[l].acc_done);
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
     }
+    spec_destroy(c->spec);
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->host_ctr) (void)hipHostFree(c->host_ctr);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -876,7 +892,24 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     DStreams st = ln.st;
     st.fb = c->st.fb;   // the (possibly caller-owned) framebuffer is shared
     hipStream_t sm = ln.stream;
+    // PATHTRACE_HIP_TRACE_LAUNCH=1 (debugging a device fault): every launch is followed by a stream synchronisation and one
+    // line on stderr, so the last line before an abort names the kernel, the bounce and the queue geometry it ran with
+    static const bool trace = getenv("PATHTRACE_HIP_TRACE_LAUNCH") != nullptr;
+    SpecJob *spec = (c->spec && spec_poll(c->spec) == 1) ? c->spec : nullptr;   // one decision per batch
+    auto traced = [&](const char *what, int bounce, const DBatch &q) -> int {
+        if (!trace) return 0;
+        const hipError_t e = hipStreamSynchronize(sm);
+        static auto last = std::chrono::steady_clock::now();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pt launch] lane %d %s bounce %d: n_seg %d x %d -> %d x %d, perm %d/%d, npix %d ns %d s0 %d tiles %d: %s, %.1f us since the previous line\n", li, what, bounce,
+                q.n_seg, q.seg_cap, q.n_seg_out, q.seg_cap_out, q.perm, q.perm_out, q.npix, q.ns, q.s0, q.n_tiles, hipGetErrorString(e),
+                std::chrono::duration<double, std::micro>(now - last).count());
+        last = now;
+        if (e != hipSuccess) { set_err("%s failed at bounce %d: %s", what, bounce, hipGetErrorString(e)); return -1; }
+        return 0;
+    };
     { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }
+    if (traced("k_generate", -1, b)) return -1;
     int qi = 0;
     DBatch bb = b;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
@@ -885,10 +918,13 @@ static int run_batch(pt_ctx *c, const DBatch &b)
         if (bb.n_seg > 1 && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
         else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
         bb.perm = seg_perm(bb.n_seg); bb.perm_out = seg_perm(bb.n_seg_out);
-        { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm); }
+        { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm, spec); }
+        if (traced("k_extend", bounce, bb)) return -1;
         { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, bb, qi, bounce, sm); }
+        if (traced("k_shade", bounce, bb)) return -1;
         if (c->tally) launch_tally(S, st, bb, qi, c->tally + (b.tiles - c->d_tiles), sm);
-        { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, bb, bounce, sm); }
+        { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, bb, bounce, sm, spec); }
+        if (traced("k_connect", bounce, bb)) return -1;
         bb.n_seg = bb.n_seg_out; bb.seg_cap = bb.seg_cap_out;
         qi ^= 1;
     }
@@ -896,6 +932,7 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     // accumulate waits for the previous batch's accumulate, whichever lane that ran on
     if (c->last_lane >= 0 && c->last_lane != li) HIP_TRY(hipStreamWaitEvent(sm, c->lanes[c->last_lane].acc_done, 0));
     { Timer t(c, PT_K_ACCUMULATE, sm); launch_accumulate(S, st, b, sm); }
+    if (traced("k_accumulate", -1, b)) return -1;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->host_ctr, st.counters, sizeof(DCounters) * PT_COUNTER_BANKS, hipMemcpyDeviceToHost, sm));
     HIP_TRY(hipEventRecord(ln.acc_done, sm));
@@ -1205,7 +1242,7 @@ extern "C" int pt_trace_rays(pt_ctx *c, int64_t n, int32_t nr, const float *orig
             hipMalloc((void **)&d_t, nray * 4) != hipSuccess || hipMalloc((void **)&d_i, nray * 4) != hipSuccess) { set_err("pt_trace_rays: hipMalloc failed"); break; }
         if (hipMemcpy(d_o, origins, (size_t)n * 12, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_d, dirs, nray * 12, hipMemcpyHostToDevice) != hipSuccess) { set_err("pt_trace_rays: upload failed"); break; }
-        launch_trace(c->S, c->lanes[0].st, n, nr, d_o, d_d, k0, k1, vol_dim, d_t, d_i, c->stream);
+        launch_trace(c->S, c->lanes[0].st, n, nr, d_o, d_d, k0, k1, vol_dim, d_t, d_i, c->stream, (c->spec && spec_poll(c->spec) == 1) ? c->spec : nullptr);
         if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) { set_err("pt_trace_rays: kernel failed"); break; }
         if (hipMemcpy(t_out, d_t, nray * 4, hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(id_out, d_i, nray * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("pt_trace_rays: download failed"); break; }
@@ -1254,6 +1291,45 @@ extern "C" int pt_set_lanes(pt_ctx *c, int32_t n)
     c->n_lanes = n;
     c->next_lane = 0;
     return c->n_lanes_alloc;
+}
+// The per-scene build of the traversal sweep (pt_spec.cpp).  Status: 1 = the context launches the scene's own k_extend /
+// k_connect / k_trace, 0 = still building (generic kernels meanwhile), -1 = not available (PATHTRACE_HIP_SPEC=off, no
+// hiprtc, a scene the build does not serve, a failed build: pt_last_error has the reason).  pt_spec_wait blocks until
+// the build has ended.  The image does not depend on it: both forms perform the same arithmetic.
+extern "C" int pt_spec_status(pt_ctx *c)
+{
+    if (!c) { set_err("pt_spec_status: null ctx"); return -1; }
+    if (!c->spec) { set_err("no per-scene build for this context"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int st = spec_poll(c->spec);
+    if (st < 0) set_err("per-scene build: %s", spec_log(c->spec));
+    return st;
+}
+extern "C" int pt_spec_wait(pt_ctx *c)
+{
+    if (!c) { set_err("pt_spec_wait: null ctx"); return -1; }
+    if (!c->spec) { set_err("no per-scene build for this context"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int st = spec_wait(c->spec);
+    if (st < 0) set_err("per-scene build: %s", spec_log(c->spec));
+    return st;
+}
+// Host-only check of the per-scene build (no device): compiles the module for gfx950 and returns the size of its code
+// object, < 0 on failure (pt_last_error has the compiler's log).
+extern "C" long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_samples)
+{
+    std::string table, log;
+    if (spec_header_text(scene, table) <= 0) return -2;
+    HostProgram hp;
+    if (build_program(scene, hp)) return -2;
+    bool textured = scene->background_texture >= 0;
+    for (int i = 0; i < scene->n_materials; i++) {
+        const pt_material &m = scene->materials[i];
+        textured |= m.texture >= 0 && (m.type == PT_MAT_LAMBERTIAN || m.type == PT_MAT_DIFFUSE_LIGHT || m.type == PT_MAT_ISOTROPIC);
+    }
+    const long n = spec_build_check(table, hp.geom_all != 0, textured, (light_samples % 2 == 0) ? 2 : 1, log);
+    if (n < 0) set_err("per-scene build: %s", log.c_str());
+    return n;
 }
 extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
 {

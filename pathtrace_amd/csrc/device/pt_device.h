@@ -1,8 +1,16 @@
 // Device-side scene tables and wavefront stream descriptors shared by the host code that fills them
 // (pt_context.cpp) and the gfx950 kernels (pt_kernels.hip).  Plain structs; HIP only for float4/uint2.
 #pragma once
+#ifdef __HIPCC_RTC__
+// hiprtc (the per-scene build, pt_spec.cpp) keeps the fixed-width integers in a namespace of its own
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+typedef signed long long int64_t;
+typedef unsigned long long uint64_t;
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace ptd {
 

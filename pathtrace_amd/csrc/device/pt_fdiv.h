@@ -15,7 +15,9 @@
 // the quotient is zero or within [2^-125, 2^126].  tools/divcheck/divcheck.hip compares this against `n / d` on the chip
 // for every denominator bit pattern and ~10^11 operand pairs inside and on the edges of the precondition.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 
 namespace ptd {
 

@@ -21,14 +21,30 @@
 //    not deterministic; per-path arithmetic does not depend on it, and k_accumulate adds a pixel's samples in sample order.
 //  * All streams are float4 / float2 planes indexed by queue position: each wave-level load or store is
 //    one fully coalesced 1 KiB / 512 B transaction.
+#ifdef __HIPCC_RTC__
+// hiprtc (the per-scene build of the sweep, pt_spec.cpp) has the HIP device builtins and fixed-width integers, but no C headers
+#ifndef FLT_MAX
+#define FLT_MAX 3.40282347e+38F
+#endif
+#ifndef INFINITY
+#define INFINITY __builtin_huge_valf()
+#endif
+#ifndef NAN
+#define NAN __builtin_nanf("")
+#endif
+#else
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#endif
 
 #include "pt_device.h"
 #include "pt_fdiv.h"
+#ifndef __HIPCC_RTC__
+#include "pt_spec.h"
+#endif
 
 namespace ptd {
 
@@ -39,6 +55,9 @@ namespace ptd {
 // for statement (same functions, same operands), so the result is the same bit for bit.
 #ifdef PT_SPEC_HEADER
 #include PT_SPEC_HEADER
+#ifndef PT_SPEC_REINV
+#define PT_SPEC_REINV 0   // measurement knob: form 1 / direction again for the parent-box check instead of keeping it in registers
+#endif
 #endif
 
 #define PT_BLOCK 256
@@ -51,6 +70,10 @@ namespace ptd {
 #ifndef PT_CONNECT_WAVES_GA
 #define PT_CONNECT_WAVES_GA 4   // the same with sphere / constant_medium leaves (108 VGPRs; at 96 it spills 12, at 80 19: with_volume 24.9 -> 25.5 Grays/s
                                 // against 5 waves at the end of round 2, three_orbs / light_test equal)
+#endif
+#ifndef PT_CONNECT_PREFETCH
+#define PT_CONNECT_PREFETCH 1   // k_connect: 1 = the radiance is requested as soon as the slot is known; 2 = and the next group's shadow
+                                // records before the current group is traced (12 more VGPRs at two rays per sweep); 0 = neither
 #endif
 #define PT_PI_D 3.14159265358979323846
 #define PT_PI_F 3.14159274f
@@ -829,9 +852,18 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
         for (int r = 0; r < NR; r++) {
             const float4 *ch = S.chains + (size_t)max(cur_id[r] >> 3, 0) * 2;
             const float4 lo = ch[0], hi = ch[1];
-            const float ax = (lo.x - A.x) * inv[r].x, cx = (hi.x - A.x) * inv[r].x;
-            const float ay = (lo.y - A.y) * inv[r].y, cy = (hi.y - A.y) * inv[r].y;
-            const float az = (lo.z - A.z) * inv[r].z, cz = (hi.z - A.z) * inv[r].z;
+#if defined(PT_SPEC_HEADER) && PT_SPEC_REINV
+            // the straight-line sweep is short of registers, not of issue slots: 1 / direction is formed again here (the same
+            // three quotients) instead of living in registers across every leaf; the empty asm keeps hipcc from reusing the first
+            float bx = B[r].x, by = B[r].y, bz = B[r].z;
+            asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz));
+            const v3 inv_r = V(fdiv(1.0f, bx), fdiv(1.0f, by), fdiv(1.0f, bz));
+#else
+            const v3 inv_r = inv[r];
+#endif
+            const float ax = (lo.x - A.x) * inv_r.x, cx = (hi.x - A.x) * inv_r.x;
+            const float ay = (lo.y - A.y) * inv_r.y, cy = (hi.y - A.y) * inv_r.y;
+            const float az = (lo.z - A.z) * inv_r.z, cz = (hi.z - A.z) * inv_r.z;
             const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
             const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
             chk = ((tmax <= tmin) && cur_id[r] >= 0) ? NAN : chk;
@@ -1959,48 +1991,58 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
         n_rays += (unsigned long long)((n - i0) < PT_BLOCK ? (n - i0) : PT_BLOCK) * L;
         if ((i0 + (int)(threadIdx.x & ~63u)) >= n) continue;
         const long long pos = seg_base + (valid ? i : i0);
+        // Memory round trips of a chunk, issued so that they overlap the sweeps instead of preceding them one by one (a wave of
+        // this kernel was parked on s_waitcnt 41 % of its life): the records of the first group of rays and the hit point go
+        // out together; the NEXT group's records are requested before the current group is traced; the radiance the result
+        // is added to is requested as soon as the slot is known, two sweeps before it is needed.
+        constexpr int R = NR > 0 ? NR : 1;
+        float4 dn[R];
+        float2 en[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) { dn[k] = sq.d[(long long)k * P + pos]; en[k] = sq.e[(long long)k * P + pos]; }
         const float4 p0 = sq.p0[pos];
         const v3 hp = V(p0.x, p0.y, p0.z);
         const int slotw = __float_as_int(p0.w);
+        const int slot = slotw & 0x7fffffff;
         uint32_t k0 = 0, k1 = 0;
         if (NV) { const uint2 kk = sq.key[pos]; k0 = kk.x; k1 = kk.y; }
+#if PT_CONNECT_PREFETCH >= 1
+        const float4 rad = st.radiance[valid ? slot : 0];   // no other lane of this launch touches the slot: each hit has one record
+#endif
         v3 lc = V(0.0f, 0.0f, 0.0f);
-        if (NR > 0) {
-            constexpr int R = NR > 0 ? NR : 1;
-            for (uint32_t kg = 0; kg < L; kg += R) {   // light_samples is a multiple of R (launch_connect)
-                v3 ldir[R], coef[R];
-                uint32_t vd[R];
-                float t[R];
-                int id[R];
+        for (uint32_t kg = 0; kg < L; kg += R) {   // light_samples is a multiple of R (launch_connect)
+            v3 ldir[R], coef[R];
+            uint32_t vd[R];
+            float t[R];
+            int id[R];
 #pragma unroll
-                for (int k = 0; k < R; k++) {
-                    const float4 d = sq.d[(long long)(kg + k) * P + pos];
-                    const float2 e = sq.e[(long long)(kg + k) * P + pos];
-                    ldir[k] = V(d.x, d.y, d.z);
-                    coef[k] = V(d.w, e.x, e.y);
-                    vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
-                }
-                world_hit<R, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
-                if (valid) {
+            for (int k = 0; k < R; k++) {
+                ldir[k] = V(dn[k].x, dn[k].y, dn[k].z);
+                coef[k] = V(dn[k].w, en[k].x, en[k].y);
+                vd[k] = base + NV + (kg + (uint32_t)k) * (3u + NV) + 3u;
+            }
+#if PT_CONNECT_PREFETCH >= 2
+            if (kg + R < L) {
 #pragma unroll
-                    for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
-                }
+                for (int k = 0; k < R; k++) { dn[k] = sq.d[(long long)(kg + R + k) * P + pos]; en[k] = sq.e[(long long)(kg + R + k) * P + pos]; }
             }
-        } else {
-            for (uint32_t k = 0; k < L; k++) {
-                const float4 d = sq.d[(long long)k * P + pos];
-                const float2 e = sq.e[(long long)k * P + pos];
-                const v3 ldir[1] = {V(d.x, d.y, d.z)};
-                const uint32_t vd[1] = {base + NV + k * (3u + NV) + 3u};
-                float t[1];
-                int id[1];
-                world_hit<1, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
-                if (valid) connect_contribution<TEX>(S, hp, ldir[0], t[0], id[0], V(d.w, e.x, e.y), pick_pdf, lc);
+#endif
+            world_hit<R, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
             }
+#if PT_CONNECT_PREFETCH < 2
+            if (kg + R < L) {
+#pragma unroll
+                for (int k = 0; k < R; k++) { dn[k] = sq.d[(long long)(kg + R + k) * P + pos]; en[k] = sq.e[(long long)(kg + R + k) * P + pos]; }
+            }
+#endif
         }
         if (valid) {
-            const int slot = slotw & 0x7fffffff;
+#if PT_CONNECT_PREFETCH < 1
             const float4 rad = st.radiance[slot];
+#endif
             v3 r = vadd(V(rad.x, rad.y, rad.z), vdiv_count(lc, n_samples));   // integrator.h:268
             if (slotw < 0) { const float4 pe = st.pending[slot]; r = vadd(r, V(pe.x, pe.y, pe.z)); }
             st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
@@ -2066,6 +2108,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
     }
 }
 
+#ifndef PT_SPEC_BUILD   // the per-scene module holds kernels only (pt_spec.cpp launches them through the module API)
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
@@ -2080,10 +2123,12 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 {
     hipLaunchKernelGGL(k_generate, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b);
 }
-void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
+void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s, SpecJob *spec)
 {
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+    // the scene's own build of the sweep when it is ready (pt_spec.cpp), else -- and on any launch error -- the generic kernel
+    if (spec && !S.walk && spec_launch_extend(spec, (int)grid.x, lds, s, S, st, b, qi, bounce) == 0) return;
 #define PT_LAUNCH_EXTEND(GA, WALK) hipLaunchKernelGGL((k_extend<GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
     if (S.walk) PT_LAUNCH_EXTEND(true, true);
     else if (S.geom_all) PT_LAUNCH_EXTEND(true, false);
@@ -2104,7 +2149,7 @@ void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, 
     else { if (lm == 1) PT_LAUNCH_SHADE(false, 1); else if (lm == 2) PT_LAUNCH_SHADE(false, 2); else PT_LAUNCH_SHADE(false, 0); }
 #undef PT_LAUNCH_SHADE
 }
-void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s)
+void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s, SpecJob *spec)
 {
     const int L = S.light_samples;
     // rays of one hit traversed together: 2 when light_samples is even, else 1.  Measured on cornell_box 1080p: 2 rays
@@ -2113,8 +2158,16 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     int nr = (L % 2 == 0) ? 2 : 1;
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     if (S.walk) nr = 1;   // the walk takes its rays one at a time
+    // The module's k_connect is the same ISA as a statically linked build of the specialised kernel, yet launched through
+    // the module API it runs 1.4 x slower than that build (20.4 against 13.9 ms per 64 spp; k_extend 4.9 against 4.7), for a
+    // reason not found; the statically linked gain is 3 % of this kernel anyway (two rays per sweep already
+    // share the op fetch).  So shadow rays keep the generic kernel unless PATHTRACE_HIP_SPEC_CONNECT=1 asks for the module's.
+    const bool spec_connect = getenv("PATHTRACE_HIP_SPEC_CONNECT") != nullptr;   // read per launch: the tests switch it
+    if (!spec_connect) spec = nullptr;
+    if (spec && !S.walk && L % spec_connect_nr(spec) == 0) nr = spec_connect_nr(spec);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
+    if (spec && !S.walk && nr == spec_connect_nr(spec) && spec_launch_connect(spec, (int)grid.x, lds, s, S, st, b, bounce) == 0) return;
 #define PT_LAUNCH_CONNECT(NR, TEX, GA, WALK) hipLaunchKernelGGL((k_connect<NR, TEX, GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
 #define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA, false); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA, false); else PT_LAUNCH_CONNECT(1, TEX, GA, false); }
     if (S.walk) { if (S.textured) PT_LAUNCH_CONNECT(1, true, true, true); else PT_LAUNCH_CONNECT(1, false, true, true); }
@@ -2124,10 +2177,11 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
 #undef PT_LAUNCH_CONNECT
 }
 void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
-                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s)
+                  uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s, SpecJob *spec)
 {
     const int blocks = persistent_grid((n + PT_BLOCK - 1) / PT_BLOCK);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * nr * PT_BLOCK * sizeof(float2);
+    if (spec && !S.walk && spec_launch_trace(spec, nr, blocks, lds, s, S, st, n, org, dir, k0, k1, vol_dim, t_out, id_out) == 0) return;
 #define PT_LAUNCH_TRACE(NR, GA, WALK) hipLaunchKernelGGL((k_trace<NR, GA, WALK>), dim3(blocks), dim3(PT_BLOCK), lds, s, S, S.ops, st, n, org, dir, k0, k1, vol_dim, t_out, id_out)
     if (S.walk) { if (nr == 4) PT_LAUNCH_TRACE(4, true, true); else if (nr == 2) PT_LAUNCH_TRACE(2, true, true); else PT_LAUNCH_TRACE(1, true, true); }
     else if (S.geom_all) { if (nr == 4) PT_LAUNCH_TRACE(4, true, false); else if (nr == 2) PT_LAUNCH_TRACE(2, true, false); else PT_LAUNCH_TRACE(1, true, false); }
@@ -2241,5 +2295,7 @@ void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hip
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(PT_BLOCK), 0, s, S, st, b);
 }
+
+#endif  // PT_SPEC_BUILD
 
 }  // namespace ptd

@@ -20,6 +20,10 @@ ORACLE_SCENES = ALL_SCENES
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # pt_create builds the traversal kernels once more per scene (hiprtc, 1.5 - 3 s, on a thread the context joins when it
+    # is destroyed).  The suite creates hundreds of short-lived contexts: the per-scene build is off here and switched on by
+    # the tests that hold it to the same bits (tests/test_gpu_spec.py, tests/test_spec_build.py); bench.py always uses it.
+    os.environ.setdefault("PATHTRACE_HIP_SPEC", "off")
 
 
 def scene_path(name):

@@ -1,0 +1,41 @@
+"""The per-scene build of the traversal sweep (pt_spec.cpp), host side: the scene's program as a compile-time table and the
+hiprtc build of pt_kernels.hip for it -- hiprtc cross-compiles gfx950 without a GPU, so that part is checked here."""
+import re
+
+import pytest
+
+import pathtrace_amd as pt
+from conftest import ALL_SCENES, scene_path
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume", "textured_room"])
+def test_the_module_of_a_scene_compiles_for_gfx950(scene):
+    sc = pt.Scene(scene_path(scene), 320, 180)
+    assert pt.spec_build_check(sc, 4) > 20000       # a code object with k_extend, k_connect and three k_trace
+    assert pt.spec_build_check(sc, 3) > 20000       # odd light_samples: one shadow ray per sweep
+
+
+@pytest.mark.parametrize("scene", ALL_SCENES)
+def test_the_table_is_the_fast_program(scene):
+    sc = pt.Scene(scene_path(scene), 320, 180)
+    text = pt.spec_header(sc)
+    n = int(re.search(r"#define PT_SPEC_N (\d+)", text).group(1))
+    rows = re.findall(r"^  \{([-0-9, ]+)\},$", text, re.M)
+    assert len(rows) == n and all(len(r.split(",")) == 32 for r in rows)
+    kinds = [int(r.split(",")[0]) for r in rows]
+    assert kinds[0] == 0 and 1 not in kinds         # the root's ENTER first, no COMBINE ops in the fast program
+    d = sc.desc
+    leaf_insts = [int(r.split(",")[1]) for r, k in zip(rows, kinds) if k >= 2]
+    # every instance is a leaf op (twice where bvh_node's n == 1 case made it both children, bvh.h:133-175)
+    assert set(leaf_insts) == set(range(d.n_instances)) and len(leaf_insts) <= d.n_instances + d.n_nodes
+    ga = int(re.search(r"#define PT_SPEC_GA (\d)", text).group(1))
+    assert ga == (1 if any(k >= 6 for k in kinds) else 0)
+
+
+def test_a_broken_build_reports_instead_of_raising_into_the_render(monkeypatch):
+    # PATHTRACE_HIP_SPEC_BREAK makes the build fail on purpose: the check says so; a context would keep the generic kernels
+    # (tests/test_gpu_spec.py renders through that fallback on the GPU)
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_BREAK", "1")
+    sc = pt.Scene(scene_path("three_orbs"), 64, 64)
+    with pytest.raises(pt.PathtraceError, match="fails on purpose"):
+        pt.spec_build_check(sc, 4)
