@@ -74,16 +74,20 @@ def model_bytes(kernel, d):
     return {"generate": 80 * N, "extend": 48 * E, "shade": 96 * E + 48 * H + 48 * S, "connect": 72 * S, "accumulate": 32 * N}[kernel]
 
 
-def stream_bytes(kernel, d, light_samples, n_launches, pixels):
-    """What THIS implementation's records move per kernel, from the same counter deltas: camera path 32 B + 16 B
-    radiance; hit 8 B; path record 64 B from bounce 1 on; shadow record 16 + 24 L B per hit that has one; radiance / pending
-    updates 32 B.  Smaller than the model where the records were shrunk (generate, accumulate), larger where the model's 48-byte
-    shadow record per RAY stands against 24 B per ray + 16 B per hit here."""
+def stream_bytes(kernel, d, light_samples, n_launches, pixels, generate_launches):
+    """What THIS implementation's records move per kernel, from the same counter deltas.  Camera rays are not
+    stored (bounce 0 forms them itself; no k_generate launch): hit 8 B per extension ray; path record 64 B written per
+    continuing path and read back by the next bounce (extend reads its 32-byte ray half); shadow record 16 + 24 L B per hit
+    that has one; radiance: 16 B initialised per camera sample, 32 B per update.  Smaller than the model where records were
+    shrunk or dropped, larger where the model's 48-byte shadow record per RAY stands against 24 B per ray + 16 B per hit here."""
     N, E, H, S = d["camera_samples"], d["extension_rays"], d["extension_hits"], d["shadow_rays_traced"]
     lit = S / max(light_samples, 1)
     ends = d["term_miss"] + d["term_emitter"]
-    return {"generate": 48 * N, "extend": 40 * E,
-            "shade": 40 * E + 32 * (E - N) + 64 * (E - N) + (16 + 24 * light_samples) * lit + 32 * ends,
+    fused = generate_launches == 0
+    return {"generate": 0 if fused else 48 * N,
+            "extend": (32 * (E - N) if fused else 32 * E) + 8 * E,
+            "shade": 8 * E + (64 * (E - N) if fused else 32 * E + 32 * (E - N)) + (16 * N if fused else 0) + 64 * (E - N)
+                     + (16 + 24 * light_samples) * lit + 32 * ends,
             "connect": (16 + 24 * light_samples) * lit + 32 * lit,
             "accumulate": 16 * N + 32 * pixels * n_launches}[kernel]
 
@@ -344,9 +348,9 @@ def main():
         ser = {}
         for k in ("generate", "extend", "shade", "connect", "accumulate"):
             ms, launches = kt_ser[k]["ms"], max(kt_ser[k]["launches"], 1)
-            mb = model_bytes(k, ctr_ser)
+            mb = model_bytes(k, ctr_ser) if kt_ser[k]["launches"] else 0   # no launch (k_generate: bounce 0 forms the camera rays), no bytes
             gbs = mb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            sb = stream_bytes(k, ctr_ser, 4, max(kt_ser["accumulate"]["launches"], 1), my_pixels)
+            sb = stream_bytes(k, ctr_ser, 4, max(kt_ser["accumulate"]["launches"], 1), my_pixels, kt_ser["generate"]["launches"])
             ser[k] = {"ms": round(ms, 4), "launches": launches, "model_bytes": int(mb), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                       "stream_bytes": int(sb), "stream_GBps": round(sb / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
         dom = max(("extend", "shade", "connect"), key=lambda k: kt_ser[k]["ms"])

@@ -27,7 +27,8 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
 void launch_accumulate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s);
 void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, const float *org, const float *dir, uint32_t k0, uint32_t k1,
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s, SpecJob *spec);
-void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, unsigned long long *cost, hipStream_t s);
+void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, unsigned long long *cost, hipStream_t s);
+int launch_fuses_generate();
 int launch_grid_max();
 }  // namespace ptd
 
@@ -908,8 +909,11 @@ static int run_batch(pt_ctx *c, const DBatch &b)
         if (e != hipSuccess) { set_err("%s failed at bounce %d: %s", what, bounce, hipGetErrorString(e)); return -1; }
         return 0;
     };
-    { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }
-    if (traced("k_generate", -1, b)) return -1;
+    // camera rays are formed by bounce 0's own kernels (pt_kernels.hip PT_FUSE_GENERATE); k_generate only runs when no bounce does
+    if (!launch_fuses_generate() || S.max_bounces == 0) {
+        { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }
+        if (traced("k_generate", -1, b)) return -1;
+    }
     int qi = 0;
     DBatch bb = b;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
@@ -922,7 +926,7 @@ static int run_batch(pt_ctx *c, const DBatch &b)
         if (traced("k_extend", bounce, bb)) return -1;
         { Timer t(c, PT_K_SHADE, sm); launch_shade(S, st, bb, qi, bounce, sm); }
         if (traced("k_shade", bounce, bb)) return -1;
-        if (c->tally) launch_tally(S, st, bb, qi, c->tally + (b.tiles - c->d_tiles), sm);
+        if (c->tally) launch_tally(S, st, bb, qi, bounce, c->tally + (b.tiles - c->d_tiles), sm);
         { Timer t(c, PT_K_CONNECT, sm); launch_connect(S, st, bb, bounce, sm, spec); }
         if (traced("k_connect", bounce, bb)) return -1;
         bb.n_seg = bb.n_seg_out; bb.seg_cap = bb.seg_cap_out;

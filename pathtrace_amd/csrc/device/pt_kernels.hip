@@ -75,6 +75,9 @@ namespace ptd {
 #define PT_CONNECT_PREFETCH 1   // k_connect: 1 = the radiance is requested as soon as the slot is known; 2 = and the next group's shadow
                                 // records before the current group is traced (12 more VGPRs at two rays per sweep); 0 = neither
 #endif
+#ifndef PT_FUSE_GENERATE
+#define PT_FUSE_GENERATE 1   // bounce 0 forms its camera rays itself, no k_generate launch (0: k_generate writes them, as before)
+#endif
 #define PT_PI_D 3.14159265358979323846
 #define PT_PI_F 3.14159274f
 
@@ -1330,46 +1333,68 @@ DEVI uint32_t bounce0_k1(const DScene &S, const DBatch &b, int slot)
     const uint32_t sample = (uint32_t)b.s0 + (uint32_t)slot / (uint32_t)b.npix;   // slot = s_local * npix + pixel, below 2^30
     return mix_lowbias32(sample ^ S.seed_k1);
 }
+// One camera sample: pixel jitter (renderer.h:648-649) + camera::get_ray (camera.h:38-47) for the path in `slot`
+// (= s_local * npix + batch-local pixel), and its stream RNG keys.
+struct CamRay { v3 A, B; uint32_t k0, k1; };
+DEVI CamRay camera_ray(const DScene &S, const DBatch &b, int slot)
+{
+    const uint32_t s_local = (uint32_t)slot / (uint32_t)b.npix;   // slot < 2^30 (pt_create)
+    const int pl = (int)((uint32_t)slot - s_local * (uint32_t)b.npix);
+    int pi, pj;
+    batch_pixel(b, pl, pi, pj);
+    const uint32_t pixel = (uint32_t)(pj * S.width + pi);
+    const uint32_t sample = (uint32_t)b.s0 + s_local;
+    CamRay r;
+    r.k0 = mix_lowbias32(pixel ^ S.seed_k0);
+    r.k1 = mix_lowbias32(sample ^ S.seed_k1);
+    const float u = (float)((double)pi + rnd(r.k0, r.k1, DIM_JITTER_U)) / (float)S.width;
+    const float v = (float)((double)pj + rnd(r.k0, r.k1, DIM_JITTER_V)) / (float)S.height;
+    const v3 cu = V(S.cam.u[0], S.cam.u[1], S.cam.u[2]), cv = V(S.cam.v[0], S.cam.v[1], S.cam.v[2]);
+    v3 offset = V(0.0f, 0.0f, 0.0f);
+    if (S.cam.lens_radius != 0.0f) {   // random_in_unit_disk random.h:27-34
+        float su, cu2;
+        ptm_sincos_2pi(rndf(r.k0, r.k1, DIM_LENS), su, cu2);
+        const float rv = sqrtf(rndf(r.k0, r.k1, DIM_LENS + 1));
+        const v3 rd = vscale(S.cam.lens_radius, V(cu2 * rv, su * rv, 0.0f));
+        offset = vadd(vscale(rd.x, cu), vscale(rd.y, cv));
+    }
+    const v3 origin = V(S.cam.origin[0], S.cam.origin[1], S.cam.origin[2]);
+    const v3 llc = V(S.cam.llc[0], S.cam.llc[1], S.cam.llc[2]);
+    const v3 hor = V(S.cam.horizontal[0], S.cam.horizontal[1], S.cam.horizontal[2]);
+    const v3 ver = V(S.cam.vertical[0], S.cam.vertical[1], S.cam.vertical[2]);
+    r.A = vadd(origin, offset);
+    r.B = vsub(vsub(vadd(vadd(llc, vscale(u, hor)), vscale(v, ver)), origin), offset);
+    return r;
+}
+// live entries of input segment `seg`: at bounce 0 the queue IS the batch's slots in order (slot = position), so the count
+// is arithmetic; later bounces read what the previous k_shade appended
+template <bool B0>
+DEVI int seg_live(const DQueue &q, const DBatch &b, int seg)
+{
+    if (B0) {
+        const long long rem = b.n_paths - (long long)seg * b.seg_cap;
+        return rem <= 0 ? 0 : (rem < b.seg_cap ? (int)rem : b.seg_cap);
+    }
+    return q.count[seg];
+}
+// PT_FUSE_GENERATE (default): camera rays are never stored.  k_extend and k_shade of bounce 0 form the ray of their slot
+// themselves (camera_ray above, ~160 vector instructions) instead of reading a 32-byte record that a k_generate launch
+// wrote: 96 bytes of HBM traffic less per camera sample (32 written, 32 + 32 read; 13 % of the pipeline's stream bytes)
+// and one launch less per batch.  k_generate remains for max_bounces = 0 (no bounce kernel runs) and as the A/B.
 __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DBatch b)
 {
     const int seg = blockIdx.x;
     const long long seg_base = (long long)seg * b.seg_cap;
     long long remaining = b.n_paths - seg_base;
     const int n = remaining <= 0 ? 0 : (remaining < b.seg_cap ? (int)remaining : b.seg_cap);
-    const int npix = b.npix;
     DQueue q = st.q[0];
     for (int i = threadIdx.x; i < n; i += PT_BLOCK) {
         const long long slot = seg_base + i;
-        const int s_local = (int)(slot / npix);
-        const int pl = (int)(slot - (long long)s_local * npix);
-        int pi, pj;
-        batch_pixel(b, pl, pi, pj);
-        const uint32_t pixel = (uint32_t)(pj * S.width + pi);
-        const uint32_t sample = (uint32_t)(b.s0 + s_local);
-        const uint32_t k0 = mix_lowbias32(pixel ^ S.seed_k0);
-        const uint32_t k1 = mix_lowbias32(sample ^ S.seed_k1);
-        float u = (float)((double)pi + rnd(k0, k1, DIM_JITTER_U)) / (float)S.width;
-        float v = (float)((double)pj + rnd(k0, k1, DIM_JITTER_V)) / (float)S.height;
-        v3 cu = V(S.cam.u[0], S.cam.u[1], S.cam.u[2]), cv = V(S.cam.v[0], S.cam.v[1], S.cam.v[2]);
-        v3 offset = V(0.0f, 0.0f, 0.0f);
-        if (S.cam.lens_radius != 0.0f) {   // random_in_unit_disk random.h:27-34
-            float su, cu2;
-            ptm_sincos_2pi(rndf(k0, k1, DIM_LENS), su, cu2);
-            float rv = sqrtf(rndf(k0, k1, DIM_LENS + 1));
-            v3 rd = vscale(S.cam.lens_radius, V(cu2 * rv, su * rv, 0.0f));
-            offset = vadd(vscale(rd.x, cu), vscale(rd.y, cv));
-        }
-        v3 origin = V(S.cam.origin[0], S.cam.origin[1], S.cam.origin[2]);
-        v3 llc = V(S.cam.llc[0], S.cam.llc[1], S.cam.llc[2]);
-        v3 hor = V(S.cam.horizontal[0], S.cam.horizontal[1], S.cam.horizontal[2]);
-        v3 ver = V(S.cam.vertical[0], S.cam.vertical[1], S.cam.vertical[2]);
-        v3 A = vadd(origin, offset);
-        v3 B = vsub(vsub(vadd(vadd(llc, vscale(u, hor)), vscale(v, ver)), origin), offset);
+        const CamRay r = camera_ray(S, b, (int)slot);
         // A camera path's record is 32 bytes: beta = 1, attenuation = 0 and last_bsdf_pdf = -1 (integrator.h:183) are constants
-        // and k1 follows from the slot (bounce0_state below); k0 rides in the pdf's place.  k_generate is a pure store
-        // stream and k_shade's first launch moves 4.4 TB/s: 64 bytes less per camera sample.
-        q.r0[slot] = make_float4(A.x, A.y, A.z, __int_as_float((int)slot));
-        q.r1[slot] = make_float4(B.x, B.y, B.z, __uint_as_float(k0));
+        // and k1 follows from the slot (bounce0_k1); k0 rides in the pdf's place.
+        q.r0[slot] = make_float4(r.A.x, r.A.y, r.A.z, __int_as_float((int)slot));
+        q.r1[slot] = make_float4(r.B.x, r.B.y, r.B.z, __uint_as_float(r.k0));
         st.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (threadIdx.x == 0) {
@@ -1383,7 +1408,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_generate(DScene S, DStreams st, DB
 // ------------------------------------------------------------------------------------------------
 // extend: closest hit of every live path's ray (integrator.h:192-193)
 // ------------------------------------------------------------------------------------------------
-template <bool GA, bool WALK>
+// B0: the bounce-0 instantiation of a batch whose camera rays are not stored (PT_FUSE_GENERATE): it forms them itself.  The
+// other instantiation carries none of that code (the camera's 19 scalars cost the bounce loop 45 spilled SGPRs when the
+// choice was a run-time branch).
+template <bool GA, bool WALK, bool B0>
 __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -1406,14 +1434,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // (chunk, seg) of the next chunk advance by the grid stride without a division per chunk
     ChunkWalk nx;
     nx.init(b.n_seg, b.perm);
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx.seg] : 0;
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
         // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
         // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
         const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
         nx.advance();
-        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx.seg];
+        if (c + (int)gridDim.x < total_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
         if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
             // zero the counters this bounce's shade will append to (segment g -> g >> 1; every output segment has an
             // even source).  The other path queue and the shadow queue are idle now: their last readers were the
@@ -1432,11 +1460,19 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         // whole wave beyond the end: nothing to do (wave-uniform exit keeps the sweep convergent)
         if ((i0 + (int)(threadIdx.x & ~63u)) >= n) continue;
         const long long pos = seg_base + (valid ? i : i0);
-        float4 r0 = q.r0[pos], r1 = q.r1[pos];
+        float4 r0, r1;
         uint32_t k0 = 0, k1 = 0;
-        if (has_vol) {
-            if (bounce == 0) { k0 = __float_as_uint(r1.w); k1 = bounce0_k1(S, b, __float_as_int(r0.w)); }   // see k_generate
-            else { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
+        if (B0) {   // the camera ray of the slot, formed here (position = slot at bounce 0)
+            const CamRay cr = camera_ray(S, b, (int)pos);
+            r0 = make_float4(cr.A.x, cr.A.y, cr.A.z, 0.0f);
+            r1 = make_float4(cr.B.x, cr.B.y, cr.B.z, 0.0f);
+            k0 = cr.k0; k1 = cr.k1;
+        } else {
+            r0 = q.r0[pos]; r1 = q.r1[pos];
+            if (has_vol) {
+                if (bounce == 0) { k0 = __float_as_uint(r1.w); k1 = bounce0_k1(S, b, __float_as_int(r0.w)); }   // see k_generate
+                else { k0 = __float_as_uint(q.s0[pos].w); k1 = __float_as_uint(q.s1[pos].w); }
+            }
         }
         float t[1];
         int id[1];
@@ -1454,6 +1490,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     if (threadIdx.x == 0 && n_rays) {
         atomicAdd(&counter_bank(st.counters)->rays, n_rays);
         atomicAdd(&counter_bank(st.counters)->ext_rays, n_rays);
+        if (B0) atomicAdd(&counter_bank(st.counters)->camera_samples, n_rays);   // every camera sample is extended once
     }
 }
 
@@ -1528,7 +1565,7 @@ DEVI float material_value_of(int type, float cosine)
 // LM: how the light of an NEE sample is found -- 1: the scene has one light (scalar records), 2: two lights (both records
 // scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
 // of the others.
-template <bool TEX, int LM, bool STAGE>
+template <bool TEX, int LM, bool STAGE, bool B0>   // B0: see k_extend
 __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
@@ -1559,12 +1596,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     float2 *const st_e = reinterpret_cast<float2 *>(sh_stage + (size_t)L * PT_BLOCK) + threadIdx.x;
     ChunkWalk nx;   // see k_extend
     nx.init(b.n_seg, b.perm);
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? q.count[nx.seg] : 0;   // one chunk ahead, see k_extend
+    int n_ahead = ((int)blockIdx.x < total_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;   // one chunk ahead, see k_extend
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
         const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
         nx.advance();
-        if (c + (int)gridDim.x < total_chunks) n_ahead = q.count[nx.seg];
+        if (c + (int)gridDim.x < total_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap;
@@ -1615,18 +1652,30 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         int slot = 0, mat_type = 0;
         if (valid) {
             const long long pos = seg_base + i;
-            const float4 r0 = q.r0[pos], r1 = q.r1[pos];
-            float4 s0, s1;
+            float4 r0, r1, s0, s1;
             const float2 h = st.hit[pos];
+            float last_bsdf_pdf;
+            if (B0) {            // a camera path: the ray of the slot is formed here, like k_extend formed it (position = slot at
+                                 // bounce 0); beta = 1, attenuation = 0 and last_bsdf_pdf = -1 (integrator.h:183) are constants
+                const CamRay cr = camera_ray(S, b, (int)pos);
+                r0 = make_float4(cr.A.x, cr.A.y, cr.A.z, __int_as_float((int)pos));
+                r1 = make_float4(cr.B.x, cr.B.y, cr.B.z, -1.0f);
+                s0 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(cr.k0));
+                s1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(cr.k1));
+                // nobody has written this sample's radiance yet: start it here (a plain store; k_generate's part of the job)
+                st.radiance[pos] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                r0 = q.r0[pos]; r1 = q.r1[pos];
+                if (bounce == 0) {   // a camera path: 32-byte record, the rest are constants (k_generate)
+                    s0 = make_float4(1.0f, 1.0f, 1.0f, r1.w);
+                    s1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bounce0_k1(S, b, __float_as_int(r0.w))));
+                    r1.w = -1.0f;
+                } else { s0 = q.s0[pos]; s1 = q.s1[pos]; }
+            }
             const v3 A = V(r0.x, r0.y, r0.z);
             const v3 B = V(r1.x, r1.y, r1.z);
             slot = __float_as_int(r0.w);
-            float last_bsdf_pdf = r1.w;
-            if (bounce == 0) {   // a camera path: 32-byte record, the rest are constants (k_generate)
-                s0 = make_float4(1.0f, 1.0f, 1.0f, r1.w);
-                s1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(bounce0_k1(S, b, slot)));
-                last_bsdf_pdf = -1.0f;
-            } else { s0 = q.s0[pos]; s1 = q.s1[pos]; }
+            last_bsdf_pdf = r1.w;
             beta = V(s0.x, s0.y, s0.z);
             att = V(s1.x, s1.y, s1.z);
             k0 = __float_as_uint(s0.w);
@@ -2128,26 +2177,30 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
     const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
     // the scene's own build of the sweep when it is ready (pt_spec.cpp), else -- and on any launch error -- the generic kernel
-    if (spec && !S.walk && spec_launch_extend(spec, (int)grid.x, lds, s, S, st, b, qi, bounce) == 0) return;
-#define PT_LAUNCH_EXTEND(GA, WALK) hipLaunchKernelGGL((k_extend<GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
+    if (spec && !S.walk && spec_launch_extend(spec, PT_FUSE_GENERATE && bounce == 0, (int)grid.x, lds, s, S, st, b, qi, bounce) == 0) return;
+#define PT_LAUNCH_EXTEND_B(GA, WALK, B0) hipLaunchKernelGGL((k_extend<GA, WALK, B0>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
+#define PT_LAUNCH_EXTEND(GA, WALK) do { if (PT_FUSE_GENERATE && bounce == 0) PT_LAUNCH_EXTEND_B(GA, WALK, true); else PT_LAUNCH_EXTEND_B(GA, WALK, false); } while (0)
     if (S.walk) PT_LAUNCH_EXTEND(true, true);
     else if (S.geom_all) PT_LAUNCH_EXTEND(true, false);
     else PT_LAUNCH_EXTEND(false, false);
+#undef PT_LAUNCH_EXTEND_B
 #undef PT_LAUNCH_EXTEND
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
     const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
     const size_t lds = b.stage_shadow ? (size_t)S.light_samples * PT_BLOCK * (sizeof(float4) + sizeof(float2)) : 0;
-#define PT_LAUNCH_SHADE(TEX, LM)                                                                                                         \
+#define PT_LAUNCH_SHADE_B(TEX, LM, B0)                                                                                                   \
     do {                                                                                                                                \
-        if (b.stage_shadow) hipLaunchKernelGGL((k_shade<TEX, LM, true>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce); \
-        else hipLaunchKernelGGL((k_shade<TEX, LM, false>), grid, block, 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);                 \
+        if (b.stage_shadow) hipLaunchKernelGGL((k_shade<TEX, LM, true, B0>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce); \
+        else hipLaunchKernelGGL((k_shade<TEX, LM, false, B0>), grid, block, 0, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce);                 \
     } while (0)
+#define PT_LAUNCH_SHADE(TEX, LM) do { if (PT_FUSE_GENERATE && bounce == 0) PT_LAUNCH_SHADE_B(TEX, LM, true); else PT_LAUNCH_SHADE_B(TEX, LM, false); } while (0)
     const int lm = S.n_lights == 1 ? 1 : (S.n_lights == 2 ? 2 : 0);   // cornell_box_small_lights 1080p: 2 = 21.1, 0 = 20.8 Grays/s
     if (S.textured) { if (lm == 1) PT_LAUNCH_SHADE(true, 1); else if (lm == 2) PT_LAUNCH_SHADE(true, 2); else PT_LAUNCH_SHADE(true, 0); }
     else { if (lm == 1) PT_LAUNCH_SHADE(false, 1); else if (lm == 2) PT_LAUNCH_SHADE(false, 2); else PT_LAUNCH_SHADE(false, 0); }
 #undef PT_LAUNCH_SHADE
+#undef PT_LAUNCH_SHADE_B
 }
 void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bounce, hipStream_t s, SpecJob *spec)
 {
@@ -2208,14 +2261,15 @@ DEVI int tile_of_slot(const DBatch &b, int slot)
     }
     return lo;
 }
-__global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int qi, int light_samples, unsigned long long *__restrict__ cost)
+__global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int qi, int bounce, int light_samples, unsigned long long *__restrict__ cost)
 {
     const DQueue q = st.q[qi];
     const int cps = b.seg_cap / PT_BLOCK, total_chunks = b.n_seg * cps;
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {           // the paths this bounce extended
         const int seg = c / cps, i = (c - seg * cps) * PT_BLOCK + (int)threadIdx.x;
-        if (i >= q.count[seg]) continue;
-        const int slot = __float_as_int(q.r0[(long long)seg * b.seg_cap + i].w);
+        if (i >= ((PT_FUSE_GENERATE && bounce == 0) ? seg_live<true>(q, b, seg) : seg_live<false>(q, b, seg))) continue;
+        const long long pos = (long long)seg * b.seg_cap + i;
+        const int slot = (PT_FUSE_GENERATE && bounce == 0) ? (int)pos : __float_as_int(q.r0[pos].w);
         atomicAdd(cost + tile_of_slot(b, slot), 1ull);
     }
     const int cps_o = b.seg_cap_out / PT_BLOCK, total_o = b.n_seg_out * cps_o;
@@ -2226,11 +2280,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int q
         atomicAdd(cost + tile_of_slot(b, slot), (unsigned long long)light_samples);
     }
 }
-void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, unsigned long long *cost, hipStream_t s)
+void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, unsigned long long *cost, hipStream_t s)
 {
     const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
-    hipLaunchKernelGGL(k_tally, grid, block, 0, s, st, b, qi, S.light_samples, cost);
+    hipLaunchKernelGGL(k_tally, grid, block, 0, s, st, b, qi, bounce, S.light_samples, cost);
 }
+int launch_fuses_generate() { return PT_FUSE_GENERATE; }
 
 // ------------------------------------------------------------------------------------------------
 // multi-GPU exchange (pt_multi.cpp): a device sends only the pixels of the tiles it owns.  rects = n x (x0, y0, x1, y1),

@@ -78,7 +78,7 @@ std::mutex g_rtc_mutex;   // one compile at a time (comgr is heavy, and the cach
 
 struct CodeObject {
     std::vector<char> code;
-    std::string name_extend, name_connect, name_trace[3];
+    std::string name_extend[2], name_connect, name_trace[3];   // k_extend: [1] = the bounce-0 instantiation (forms its camera rays)
     int connect_nr = 2;
 };
 std::map<std::string, std::shared_ptr<CodeObject>> g_cache;   // key: table text + flags
@@ -110,12 +110,13 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     auto obj = std::make_shared<CodeObject>();
     obj->connect_nr = connect_nr;
     const char *ga = geom_all ? "true" : "false", *tex = textured ? "true" : "false";
-    char e_ext[128], e_con[128], e_tr[3][128];
-    snprintf(e_ext, sizeof e_ext, "ptd::k_extend<%s, false>", ga);
+    char e_ext[2][128], e_con[128], e_tr[3][128];
+    snprintf(e_ext[0], sizeof e_ext[0], "ptd::k_extend<%s, false, false>", ga);
+    snprintf(e_ext[1], sizeof e_ext[1], "ptd::k_extend<%s, false, true>", ga);
     snprintf(e_con, sizeof e_con, "ptd::k_connect<%d, %s, %s, false>", connect_nr, tex, ga);
     const int trs[3] = {1, 2, 4};
     for (int i = 0; i < 3; i++) snprintf(e_tr[i], sizeof e_tr[i], "ptd::k_trace<%d, %s, false>", trs[i], ga);
-    bool ok = g_rtc.AddNameExpression(prog, e_ext) == 0 && g_rtc.AddNameExpression(prog, e_con) == 0;
+    bool ok = g_rtc.AddNameExpression(prog, e_ext[0]) == 0 && g_rtc.AddNameExpression(prog, e_ext[1]) == 0 && g_rtc.AddNameExpression(prog, e_con) == 0;
     for (int i = 0; i < 3; i++) ok = ok && g_rtc.AddNameExpression(prog, e_tr[i]) == 0;
     // the product's flags (pathtrace_amd/build.py): no FMA contraction, IEEE division and square root; the specialised k_connect
     // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17, measured +10 % instead of -4 %) and without the early
@@ -132,8 +133,10 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
         return nullptr;
     }
     const char *lowered = nullptr;
-    ok = g_rtc.GetLoweredName(prog, e_ext, &lowered) == 0 && lowered;
-    if (ok) obj->name_extend = lowered;
+    ok = g_rtc.GetLoweredName(prog, e_ext[0], &lowered) == 0 && lowered;
+    if (ok) obj->name_extend[0] = lowered;
+    ok = ok && g_rtc.GetLoweredName(prog, e_ext[1], &lowered) == 0 && lowered;
+    if (ok) obj->name_extend[1] = lowered;
     ok = ok && g_rtc.GetLoweredName(prog, e_con, &lowered) == 0 && lowered;
     if (ok) obj->name_connect = lowered;
     for (int i = 0; i < 3 && ok; i++) { ok = g_rtc.GetLoweredName(prog, e_tr[i], &lowered) == 0 && lowered; if (ok) obj->name_trace[i] = lowered; }
@@ -161,7 +164,7 @@ struct SpecJob {
     std::string log;
     // loaded on the context's device by whoever first sees `done` (hipModuleLoadData needs the device current)
     hipModule_t module = nullptr;
-    hipFunction_t f_extend = nullptr, f_connect = nullptr, f_trace[3] = {nullptr, nullptr, nullptr};
+    hipFunction_t f_extend[2] = {nullptr, nullptr}, f_connect = nullptr, f_trace[3] = {nullptr, nullptr, nullptr};
     std::atomic<int> state{0};   // 0 building, 1 module loaded, -1 failed
 };
 
@@ -187,7 +190,7 @@ static void finish(SpecJob *j)
     if (j->state.load() != 0) return;
     if (!j->obj) { j->state.store(-1); return; }
     bool ok = hipModuleLoadData(&j->module, j->obj->code.data()) == hipSuccess;
-    ok = ok && hipModuleGetFunction(&j->f_extend, j->module, j->obj->name_extend.c_str()) == hipSuccess;
+    for (int i = 0; i < 2; i++) ok = ok && hipModuleGetFunction(&j->f_extend[i], j->module, j->obj->name_extend[i].c_str()) == hipSuccess;
     ok = ok && hipModuleGetFunction(&j->f_connect, j->module, j->obj->name_connect.c_str()) == hipSuccess;
     for (int i = 0; i < 3; i++) ok = ok && hipModuleGetFunction(&j->f_trace[i], j->module, j->obj->name_trace[i].c_str()) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); j->log = "hipModuleLoadData / hipModuleGetFunction failed for the per-scene module"; }
@@ -236,11 +239,11 @@ static int launch(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **a
 }
 
 // the module's kernels, launched with the generic kernels' argument lists (pt_kernels.hip k_extend / k_connect / k_trace)
-int spec_launch_extend(SpecJob *j, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce)
+int spec_launch_extend(SpecJob *j, bool b0, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce)
 {
     void *args[] = {(void *)&S, (void *)&S.ops, (void *)&S.insts, (void *)&S.prims, (void *)&S.mats, (void *)&S.lights, (void *)&S.emit,
                     (void *)&st, (void *)&b, (void *)&qi, (void *)&bounce};
-    return launch(j->f_extend, grid, lds, s, args);
+    return launch(j->f_extend[b0 ? 1 : 0], grid, lds, s, args);
 }
 int spec_launch_connect(SpecJob *j, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int bounce)
 {

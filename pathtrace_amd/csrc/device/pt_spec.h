@@ -15,7 +15,7 @@ int spec_wait(SpecJob *j);    // blocks until the build has ended, then as spec_
 const char *spec_log(SpecJob *j);
 void spec_destroy(SpecJob *j);
 int spec_connect_nr(SpecJob *j);
-int spec_launch_extend(SpecJob *j, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce);
+int spec_launch_extend(SpecJob *j, bool b0, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce);
 int spec_launch_connect(SpecJob *j, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, const DBatch &b, int bounce);
 int spec_launch_trace(SpecJob *j, int nr, int grid, size_t lds, hipStream_t s, const DScene &S, const DStreams &st, long long n, const float *org,
                       const float *dir, uint32_t k0, uint32_t k1, uint32_t vol_dim, float *t_out, int *id_out);

@@ -18,6 +18,17 @@ import sys
 from collections import defaultdict
 
 KERNELS = ("generate", "extend", "shade", "connect", "accumulate")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha16():
+    """The hash bench.py compares before it quotes a PMC summary: these counters describe THIS build of the kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_device.h", "pt_fdiv.h"):
+        with open(os.path.join(ROOT, "pathtrace_amd", "csrc", "device", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def find(d, suffix):
@@ -37,6 +48,7 @@ def pmc_per_launch(d, counter):
     if not f:
         return {}
     per = defaultdict(lambda: defaultdict(float))   # kernel -> dispatch id -> value
+    dur = defaultdict(dict)
     with open(f) as fh:
         for row in csv.DictReader(fh):
             if row.get("Counter_Name") != counter:
@@ -44,7 +56,8 @@ def pmc_per_launch(d, counter):
             k = kname(row.get("Kernel_Name", ""))
             if k:
                 per[k][row.get("Dispatch_Id")] += float(row.get("Counter_Value", 0))
-    return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items() if v}
+                dur[k][row.get("Dispatch_Id")] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+    return {k: (sum(v.values()) / len(v), len(v), sum(dur[k].values()) / len(v)) for k, v in per.items() if v}
 
 
 def insts_per_kernel(d):
@@ -128,33 +141,39 @@ def main():
         shutil.copy(b, os.path.join(out, tag + "_bench_default.json"))
     fetch = pmc_per_launch(os.path.join(d, tag + "_pmc_fetch"), "FETCH_SIZE")
     write = pmc_per_launch(os.path.join(d, tag + "_pmc_write"), "WRITE_SIZE")
-    res = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_gpu.sh " + tag + "), "
-                   "bench.py --steps 4 --warmup 1 (16 spp batches, 1080p); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
-                   "the gfx950 correction for wide coalesced reads; averages over all launches of all bounces"}
+    sha = kernel_source_sha16()
+    res = {"kernel_source_sha16": sha,
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_gpu.sh " + tag + "), "
+                   "one lane (every dispatch alone on the chip); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                   "the gfx950 correction for wide coalesced reads; averages over all launches of all bounces; "
+                   "seconds_per_launch / TBps from the FETCH pass's own dispatch timestamps"}
     for k in KERNELS:
         if k in fetch and k in write:
-            fk, n = fetch[k]
-            wk, _ = write[k]
+            fk, n, sec = fetch[k]
+            wk, _, _ = write[k]
+            b = int((2 * fk + wk) * 1024)
             res[k] = {"launches_sampled": n, "FETCH_SIZE_KB_per_launch": round(fk, 1), "WRITE_SIZE_KB_per_launch": round(wk, 1),
-                      "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+                      "hbm_bytes_per_launch": b, "seconds_per_launch": round(sec, 9), "TBps": round(b / sec / 1e12, 3) if sec > 0 else None}
     json.dump(res, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1)
     ins = insts_per_kernel(os.path.join(d, tag + "_pmc_insts"))
     if ins:
+        ins["kernel_source_sha16"] = sha
         ins["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS "
                        "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/profile_gpu.sh " + tag + "), bench.py --steps 4 "
                        "--warmup 1; valu_issue_fraction = wave64 VALU instructions per second / (1024 SIMDs * clock / 2), the FP32 mul/add/fma rate")
         json.dump(ins, open(os.path.join(out, tag + "_instruction_mix.json"), "w"), indent=1)
-        print(json.dumps({k: v for k, v in ins.items() if k != "note"}))
+        print(json.dumps({k: v for k, v in ins.items() if isinstance(v, dict)}))
     ws = wait_states(os.path.join(d, tag + "_pmc_wait"))
     if ws:
+        ws["kernel_source_sha16"] = sha
         ws["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
                       "SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE with PATHTRACE_HIP_LANES=1 (tools/profile_gpu.sh " + tag + " pass 5): every kernel "
                       "alone on the chip; fractions are of SQ_WAVE_CYCLES, i.e. of a wave's life")
         json.dump(ws, open(os.path.join(out, tag + "_wait_states.json"), "w"), indent=1)
-        print(json.dumps({k: v for k, v in ws.items() if k != "note"}))
+        print(json.dumps({k: v for k, v in ws.items() if isinstance(v, dict)}))
     if ins:   # instruction totals of the run: the first thing to compare with the previous profile (same workload every time)
-        print("total vector instructions (1e9):", {k: round(v["valu_per_wave"] * v["waves"] / 1e9, 3) for k, v in ins.items() if k != "note"})
-    print(json.dumps({k: v for k, v in res.items() if k != "note"}))
+        print("total vector instructions (1e9):", {k: round(v["valu_per_wave"] * v["waves"] / 1e9, 3) for k, v in ins.items() if isinstance(v, dict)})
+    print(json.dumps({k: v for k, v in res.items() if isinstance(v, dict)}))
     if ks:
         print(open(ks).read()[:1500])
 
