@@ -1650,6 +1650,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         float new_pdf = 0.0f;
         uint32_t k0 = 0, k1 = 0;
         int slot = 0, mat_type = 0;
+        float4 rad0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // B0: this camera sample's radiance so far
         if (valid) {
             const long long pos = seg_base + i;
             float4 r0, r1, s0, s1;
@@ -1662,8 +1663,8 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 r1 = make_float4(cr.B.x, cr.B.y, cr.B.z, -1.0f);
                 s0 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(cr.k0));
                 s1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(cr.k1));
-                // nobody has written this sample's radiance yet: start it here (a plain store; k_generate's part of the job)
-                st.radiance[pos] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // nobody has written this sample's radiance yet: its sum starts at zero in a register (rad0) and is stored once,
+                // below, with whatever this bounce adds -- k_generate's initialisation and this bounce's read-modify-writes in one store
             } else {
                 r0 = q.r0[pos]; r1 = q.r1[pos];
                 if (bounce == 0) {   // a camera path: 32-byte record, the rest are constants (k_generate)
@@ -1694,9 +1695,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     }
                     tex_eval(S, S.bg_tex, eu, ev, ud, bg, ea);
                 }
-                const float4 rad = st.radiance[slot];
                 const v3 add = vmul(beta, bg);
-                st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                if (B0) rad0 = make_float4(rad0.x + add.x, rad0.y + add.y, rad0.z + add.z, 0.0f);
+                else {
+                    const float4 rad = st.radiance[slot];
+                    st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                }
                 ev_miss = true;
             } else {
                 const ShadeHit hi = shade_hit(S, A, B, h.x, id);
@@ -1734,8 +1738,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                         const float weight = power_heuristic(last_bsdf_pdf, lp);
                         add = vscale(weight, vmul(beta, hit_emission));
                     }
-                    const float4 rad = st.radiance[slot];
-                    st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                    if (B0) rad0 = make_float4(rad0.x + add.x, rad0.y + add.y, rad0.z + add.z, 0.0f);
+                    else {
+                        const float4 rad = st.radiance[slot];
+                        st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
+                    }
                 }
                 shadow = true;
                 if (did_scatter) {   // integrator.h:271-316
@@ -1948,10 +1955,15 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             const bool dark = shadow && !lit;
             n_dark += __popcll(__ballot(dark));
             if (dark && pending) {   // no record for connect to add the second emitter addition after: nothing comes between
-                const float4 rad = st.radiance[slot], pe = st.pending[slot];
-                st.radiance[slot] = make_float4(rad.x + pe.x, rad.y + pe.y, rad.z + pe.z, 0.0f);
+                const float4 pe = st.pending[slot];
+                if (B0) rad0 = make_float4(rad0.x + pe.x, rad0.y + pe.y, rad0.z + pe.z, 0.0f);
+                else {
+                    const float4 rad = st.radiance[slot];
+                    st.radiance[slot] = make_float4(rad.x + pe.x, rad.y + pe.y, rad.z + pe.z, 0.0f);
+                }
             }
         }
+        if (B0 && valid) st.radiance[slot] = rad0;   // the one radiance store of a camera sample at bounce 0 (coalesced: slot = position)
         if (shadow && lit) {
             sq.p0[o] = make_float4(hp.x, hp.y, hp.z, __int_as_float(slot | (pending ? (int)0x80000000 : 0)));
             if (NV) sq.key[o] = make_uint2(k0, k1);
