@@ -86,3 +86,32 @@ def test_main_rewrites_a_preview_while_rendering(tmp_path):
     ref = tmp_path / "ref.ppm"
     pt.write_ppm(str(ref), fb, spp, 2.2)
     assert final == ref.read_bytes()
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume", "textured_room"])
+def test_reference_side_plugin_renders_through_the_renderer_protocol(scene, tmp_path):
+    """tools/integration/hip_wavefront.h -- `HipWavefront : Renderer`, compiled against the REAL reference headers in the build
+    container (make -C oracle plugin -> oracle/_ref/plugin_driver, a binary that travels with the snapshot; the reference's
+    sources do not) -- driven the way main.cpp:156-167 drives a renderer: start_render, sync_progress until is_done,
+    finalize.  The framebuffer the reference-side object ends up holding (vec3 **framebuffer, renderer.h:141) must be the
+    library's own render of the same scene and config, bit for bit."""
+    import json
+    import subprocess
+    from oracle import scene_params as sp
+    driver = os.path.join(ROOT, "oracle", "_ref", "plugin_driver")
+    if not os.path.exists(driver):
+        pytest.skip("oracle/_ref/plugin_driver was not built (needs the reference tree at build time)")
+    w, h, spp = 160, 90, 6
+    params = sp.load_scene_params(json.load(open(scene_path(scene))), base_dir=ROOT)
+    ptxt, out = tmp_path / "scene.params", tmp_path / "fb.f32"
+    ptxt.write_text(sp.to_text(params))
+    # <cfg> = W H spp max_bounces light_samples rr normal_offset only_direct block_w block_h
+    p = subprocess.run([driver, str(ptxt), "render", str(w), str(h), str(spp), "10", "4", "1", "0.0001", "0", "64", "64", str(out)],
+                       capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    got = np.fromfile(out, np.float32).reshape(h, w, 3)
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, seed=0)
+    want = r.render(spp)
+    r.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
