@@ -34,7 +34,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function", "-ldl"]
 
 
-def embed_sources() -> None:
+def embed_sources(defs=()) -> None:
     """The device sources as string literals for pt_spec.cpp (the per-scene hiprtc build compiles them again at pt_create):
     generated files, never edited and not tracked."""
     for name, src in (("kernels", "pt_kernels.hip"), ("device", "pt_device.h"), ("fdiv", "pt_fdiv.h")):
@@ -49,6 +49,15 @@ def embed_sources() -> None:
         if not os.path.exists(out) or open(out).read() != new:
             with open(out, "w") as f:
                 f.write(new)
+    # the -D flags of an A/B variant reach the per-scene hiprtc build too: the module and the library must be the same kernels
+    # (a module built with the default flags beside a library built without the live-count bound faulted: one side never
+    # wrote the words the other read).  The specialisation's own knobs are the module's business.
+    keep = [d for d in defs if d.startswith("-DPT_") and not d.startswith(("-DPT_SPEC_HEADER", "-DPT_CONNECT_WAVES", "-DPT_CONNECT_PREFETCH"))]
+    out = os.path.join(CSRC, "device", "pt_kernel_src_flags.inc")
+    new = "".join('"%s",\n' % d.replace("\\", "\\\\").replace('"', '\\"') for d in keep) + "nullptr\n"
+    if not os.path.exists(out) or open(out).read() != new:
+        with open(out, "w") as f:
+            f.write(new)
 
 
 def needs_build() -> bool:
@@ -63,7 +72,7 @@ def build(force: bool = False, verbose: bool = False, defs=(), out: str = None) 
     if out is None and not force and not needs_build():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    embed_sources()
+    embed_sources(defs)
     target = os.path.join(LIB_DIR, out) if out else LIB
     cmd = [HIPCC] + FLAGS + list(defs) + SOURCES + ["-o", target]
     if verbose:

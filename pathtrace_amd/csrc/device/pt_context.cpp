@@ -29,6 +29,7 @@ void launch_trace(const DScene &S, const DStreams &st, long long n, int nr, cons
                   uint32_t vol_dim, float *t_out, int *id_out, hipStream_t s, SpecJob *spec);
 void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, unsigned long long *cost, hipStream_t s);
 int launch_fuses_generate();
+int launch_qmax_words();
 int launch_grid_max();
 }  // namespace ptd
 
@@ -739,6 +740,7 @@ static int alloc_streams(pt_ctx *c)
             dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
             return -1;
         if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
+        if (dev_alloc(c, &st.qmax, (size_t)launch_qmax_words())) return -1;
         st.gstack = nullptr;
         st.gstack_stride = 0;
         if (c->S.stack_depth > PT_MAX_STACK) {   // deeper than the LDS short stack: a global one per lane (kernels of two lanes overlap)
@@ -909,6 +911,7 @@ static int run_batch(pt_ctx *c, const DBatch &b)
         if (e != hipSuccess) { set_err("%s failed at bounce %d: %s", what, bounce, hipGetErrorString(e)); return -1; }
         return 0;
     };
+    HIP_TRY(hipMemsetAsync(st.qmax, 0, sizeof(int32_t) * (size_t)launch_qmax_words(), sm));   // this batch's live-count maxima (chunk_limit)
     // camera rays are formed by bounce 0's own kernels (pt_kernels.hip PT_FUSE_GENERATE); k_generate only runs when no bounce does
     if (!launch_fuses_generate() || S.max_bounces == 0) {
         { Timer t(c, PT_K_GENERATE, sm); launch_generate(S, st, b, sm); }

@@ -216,6 +216,8 @@ struct DStreams {
     float4 *radiance;            // [P]: per camera sample radiance sum (rgb, unused)
     float4 *pending;             // [P]: second emitter addition (integrator.h:319), applied by connect
     float4 *fb;                  // [height*width] rgba framebuffer SUM
+    int32_t *qmax;               // [64 bounces][2 queues][64 banks] per batch, zeroed when it starts: the largest live count of any output
+                                 // segment of bounce b's path queue / shadow queue, max over the banks (pt_kernels.hip chunk_limit)
     DCounters *counters;         // [PT_COUNTER_BANKS]
     float2 *gstack;              // general sweep's short stack for trees deeper than PT_MAX_STACK: [slot][ray <= 4][gstack_stride
     int32_t gstack_stride;       // threads], NULL while the LDS stack suffices (pt_kernels.hip stack_of)

@@ -1296,6 +1296,35 @@ DEVI void batch_pixel(const DBatch &b, int pl, int &pi, int &pj)
 // segments are an arithmetic progression of stride gridDim.x, which beats against the period of the image in slot space
 // (pixels per sample / segment size) -- at 2^18 pixels per batch every workgroup saw the SAME pixels of every sample, the
 // ones over the background idled while the ones over the box did all the work (k_shade 18.0 ms against 10.9).
+// How far a launch has to look.  A queue keeps its capacity from bounce to bounce (segments merge, their slots add up) while
+// the live paths halve, so from the third bounce on almost every 256-lane chunk slot of a segment is empty, and a persistent
+// workgroup that walks all of them pays a scalar load and a compare per slot: ~150 us per k_shade launch however few paths
+// were left (half of the time of a batch's last five bounces).  The producer therefore records the largest live count of
+// any of its output segments -- every wave keeps the largest end of the ranges it reserved in a scalar register and adds
+// it with ONE fire-and-forget atomicMax per queue when it retires, into one of PT_QMAX_BANKS words picked by its workgroup
+// (DStreams::qmax; a single word serialised a million atomics per launch: k_shade 16 -> 85 ms) -- and the consumers of that
+// queue take the maximum over the banks and stop at the chunk index beyond which every segment is empty.
+// PT_CHUNK_BOUND = 0: walk every slot (A/B knob).
+#ifndef PT_CHUNK_BOUND
+#define PT_CHUNK_BOUND 1
+#endif
+#define PT_QMAX_BOUNCES 64   // bounces that have words in DStreams::qmax; later ones walk every slot
+#define PT_QMAX_BANKS 64
+// qmax[(bounce * 2 + word) * PT_QMAX_BANKS + bank], word 0 = path queue, 1 = shadow queue
+DEVI int chunk_limit(const int32_t *qmax, int word, int bounce_of_producer, int n_seg, int total_chunks)
+{
+#if PT_CHUNK_BOUND
+    if (bounce_of_producer >= 0 && bounce_of_producer < PT_QMAX_BOUNCES) {
+        const int32_t *w = qmax + (size_t)(bounce_of_producer * 2 + word) * PT_QMAX_BANKS;
+        int live = 0;
+#pragma unroll
+        for (int k = 0; k < PT_QMAX_BANKS; k++) live = max(live, w[k]);   // wave-uniform addresses: four scalar loads
+        const long long lim = (long long)((live + PT_BLOCK - 1) / PT_BLOCK) * n_seg;   // chunk-major: chunk = c / n_seg
+        return lim < total_chunks ? (int)lim : total_chunks;
+    }
+#endif
+    return total_chunks;
+}
 struct ChunkWalk {
     int chunk, k, seg, g_chunks, g_k, d_seg, n_seg;
     DEVI void init(int n_seg_, int mul)
@@ -1434,14 +1463,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // (chunk, seg) of the next chunk advance by the grid stride without a division per chunk
     ChunkWalk nx;
     nx.init(b.n_seg, b.perm);
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;
-    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
+    const int end_chunks = B0 ? total_chunks : chunk_limit(st.qmax, 0, bounce - 1, b.n_seg, total_chunks);   // see chunk_limit
+    int n_ahead = ((int)blockIdx.x < end_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;
+    for (int c = blockIdx.x; c < end_chunks; c += gridDim.x) {
         // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
         // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
         const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
         nx.advance();
-        if (c + (int)gridDim.x < total_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
+        if (c + (int)gridDim.x < end_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
         if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
             // zero the counters this bounce's shade will append to (segment g -> g >> 1; every output segment has an
             // even source).  The other path queue and the shadow queue are idle now: their last readers were the
@@ -1596,12 +1626,16 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
     float2 *const st_e = reinterpret_cast<float2 *>(sh_stage + (size_t)L * PT_BLOCK) + threadIdx.x;
     ChunkWalk nx;   // see k_extend
     nx.init(b.n_seg, b.perm);
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;   // one chunk ahead, see k_extend
-    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
+    const int end_chunks = B0 ? total_chunks : chunk_limit(st.qmax, 0, bounce - 1, b.n_seg, total_chunks);   // see chunk_limit
+    // this bounce's words of this workgroup's bank, and the largest range end this wave reserved in either queue (scalars)
+    int32_t *const qmax_out = (PT_CHUNK_BOUND && bounce < PT_QMAX_BOUNCES) ? st.qmax + (size_t)(bounce * 2) * PT_QMAX_BANKS + (blockIdx.x & (PT_QMAX_BANKS - 1)) : nullptr;
+    int wave_top[2] = {0, 0};
+    int n_ahead = ((int)blockIdx.x < end_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;   // one chunk ahead, see k_extend
+    for (int c = blockIdx.x; c < end_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
         const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
         nx.advance();
-        if (c + (int)gridDim.x < total_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
+        if (c + (int)gridDim.x < end_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap;
@@ -1796,15 +1830,16 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         n_miss += __popcll(__ballot(ev_miss)); n_hit += __popcll(__ballot(shadow)); n_rr += __popcll(__ballot(ev_rr));
         n_emit += __popcll(__ballot(ev_emit)); n_pdf += __popcll(__ballot(ev_pdf)); n_limit += __popcll(__ballot(ev_limit));
         const unsigned long long below = (1ull << lane) - 1ull;
-        auto reserve = [&](bool take, int32_t *counter) -> long long {
+        auto reserve = [&](bool take, int32_t *counter, int word) -> long long {
             const unsigned long long m = __ballot(take);
             int base_s = 0;
             if (lane == 0 && m) base_s = atomicAdd(counter, __popcll(m));
             base_s = __builtin_amdgcn_readfirstlane(base_s);
+            wave_top[word] = max(wave_top[word], m ? base_s + (int)__popcll(m) : 0);   // scalar (chunk_limit)
             return seg_base_o + base_s + __popcll(m & below);
         };
         {
-            const long long oc = reserve(cont, &qo.count[seg_o]);
+            const long long oc = reserve(cont, &qo.count[seg_o], 0);
             if (cont) {
                 qo.r0[oc] = make_float4(nA.x, nA.y, nA.z, __int_as_float(slot));
                 qo.r1[oc] = make_float4(nB.x, nB.y, nB.z, new_pdf);
@@ -1818,7 +1853,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         // cornell_box: surfaces facing away from the light, hits on the light).  Otherwise the record is reserved first and
         // the samples are stored as they are made.
         bool lit = !stage;
-        long long o = stage ? 0 : reserve(shadow, &sq.count[seg_o]);
+        long long o = stage ? 0 : reserve(shadow, &sq.count[seg_o], 1);
         const bool wave_finite = __all(!shadow || (isfinite(hp.x) && isfinite(hp.y) && isfinite(hp.z)));
         if (shadow) {
             // light sampling, integrator.h:221-243: everything up to (not including) the shadow ray's World::hit
@@ -1945,7 +1980,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             }
         }
         if (stage) {
-            o = reserve(shadow && lit, &sq.count[seg_o]);
+            o = reserve(shadow && lit, &sq.count[seg_o], 1);
             if (shadow && lit) {
                 for (uint32_t k = 0; k < L; k++) {
                     sq.d[(long long)k * P + o] = st_d[k * PT_BLOCK];
@@ -1970,6 +2005,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
         }
     }
     if (lane == 0) {
+        if (qmax_out) {   // no result awaited
+            if (wave_top[0]) atomicMax(qmax_out, wave_top[0]);
+            if (wave_top[1]) atomicMax(qmax_out + PT_QMAX_BANKS, wave_top[1]);
+        }
         DCounters *cb = counter_bank(st.counters);
         if (n_hit) atomicAdd(&cb->ext_hits, (unsigned long long)n_hit);
         if (n_miss) atomicAdd(&cb->term_miss, (unsigned long long)n_miss);
@@ -2038,12 +2077,13 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
     unsigned long long n_rays = 0;
     ChunkWalk nx;   // see k_extend
     nx.init(b.n_seg_out, b.perm_out);
-    int n_ahead = ((int)blockIdx.x < total_chunks) ? sq.count[nx.seg] : 0;   // one chunk ahead, see k_extend
-    for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
+    const int end_chunks = chunk_limit(st.qmax, 1, bounce, b.n_seg_out, total_chunks);   // see chunk_limit
+    int n_ahead = ((int)blockIdx.x < end_chunks) ? sq.count[nx.seg] : 0;   // one chunk ahead, see k_extend
+    for (int c = blockIdx.x; c < end_chunks; c += gridDim.x) {   // persistent workgroups, chunk-major, see k_extend
         const int chunk = nx.chunk, seg = nx.seg;
         const int n = n_ahead;
         nx.advance();
-        if (c + (int)gridDim.x < total_chunks) n_ahead = sq.count[nx.seg];
+        if (c + (int)gridDim.x < end_chunks) n_ahead = sq.count[nx.seg];
         const int i0 = chunk * PT_BLOCK;
         if (i0 >= n) continue;
         const long long seg_base = (long long)seg * b.seg_cap_out;
@@ -2298,6 +2338,7 @@ void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, 
     hipLaunchKernelGGL(k_tally, grid, block, 0, s, st, b, qi, bounce, S.light_samples, cost);
 }
 int launch_fuses_generate() { return PT_FUSE_GENERATE; }
+int launch_qmax_words() { return 2 * PT_QMAX_BOUNCES * PT_QMAX_BANKS; }
 
 // ------------------------------------------------------------------------------------------------
 // multi-GPU exchange (pt_multi.cpp): a device sends only the pixels of the tiles it owns.  rects = n x (x0, y0, x1, y1),

@@ -41,6 +41,10 @@ static const char kSrcDevice[] =
 static const char kSrcFdiv[] =
 #include "pt_kernel_src_fdiv.inc"
     ;
+// -D flags this library was built with beyond the defaults (A/B variants): the module must be built from the same kernels
+static const char *const kBuildFlags[] = {
+#include "pt_kernel_src_flags.inc"
+};
 
 namespace {
 // ---- hiprtc through dlopen ----
@@ -123,8 +127,9 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     // radiance request, which at this register budget is spilled the moment it arrives (k_connect 20.5 against 14.3 ms)
     const char *waves = "-DPT_CONNECT_WAVES=5";
     if (const char *e = getenv("PATHTRACE_HIP_SPEC_WAVES")) { if (!strcmp(e, "4")) waves = "-DPT_CONNECT_WAVES=4"; else if (!strcmp(e, "6")) waves = "-DPT_CONNECT_WAVES=6"; }
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", waves, "-DPT_CONNECT_PREFETCH=0"};
-    const int rc = ok ? g_rtc.CompileProgram(prog, 7, opts) : -1;
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", waves, "-DPT_CONNECT_PREFETCH=0"};
+    for (const char *const *f = kBuildFlags; *f; f++) opts.push_back(*f);
+    const int rc = ok ? g_rtc.CompileProgram(prog, (int)opts.size(), opts.data()) : -1;
     if (rc != 0) {
         size_t n = 0;
         if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) { log.resize(n); g_rtc.GetProgramLog(prog, &log[0]); }
