@@ -347,10 +347,12 @@ def main():
         # ---- roofline: rank 0's own launches of the serialised pass ----
         ser = {}
         for k in ("generate", "extend", "shade", "connect", "accumulate"):
-            ms, launches = kt_ser[k]["ms"], max(kt_ser[k]["launches"], 1)
-            mb = model_bytes(k, ctr_ser) if kt_ser[k]["launches"] else 0   # no launch (k_generate: bounce 0 forms the camera rays), no bytes
-            gbs = mb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            ms, launches = kt_ser[k]["ms"], kt_ser[k]["launches"]
             sb = stream_bytes(k, ctr_ser, 4, max(kt_ser["accumulate"]["launches"], 1), my_pixels, kt_ser["generate"]["launches"])
+            mb = model_bytes(k, ctr_ser) if launches else 0   # no launch (k_generate: bounce 0 forms the camera rays), no bytes
+            if k == "accumulate":
+                mb = sb   # the 8(d) model's 32 B framebuffer update per camera sample is per PASS here: one per pixel and launch, 16 B read per sample
+            gbs = mb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             ser[k] = {"ms": round(ms, 4), "launches": launches, "model_bytes": int(mb), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                       "stream_bytes": int(sb), "stream_GBps": round(sb / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
         dom = max(("extend", "shade", "connect"), key=lambda k: kt_ser[k]["ms"])
@@ -360,8 +362,8 @@ def main():
         roofline = {"bound": "hbm", "kernel": "k_" + dom,
                     "achieved": ser[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ser[dom]["frac"],
                     "traffic": pmc["traffic_bytes_per_launch"],
-                    "avg_launch_ms": round(kt_ser[dom]["ms"] / ser[dom]["launches"], 5), "launches": ser[dom]["launches"],
-                    "bytes_per_launch_model": round(ser[dom]["model_bytes"] / ser[dom]["launches"], 1),
+                    "avg_launch_ms": round(kt_ser[dom]["ms"] / max(ser[dom]["launches"], 1), 5), "launches": ser[dom]["launches"],
+                    "bytes_per_launch_model": round(ser[dom]["model_bytes"] / max(ser[dom]["launches"], 1), 1),
                     "how": "achieved = SURVEY 8d model bytes of the dominant kernel over its launches / their summed HIP-event time, "
                            "both from the serialised pass below (one lane: the kernel has the chip to itself)",
                     "serialised": {"steps": ser_spp // SPP_PER_STEP, "spp": ser_spp, "lanes": 1, "wall_ms": round(dt_ser * 1e3, 3),
@@ -375,6 +377,11 @@ def main():
                                    "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
                                    "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)},
                     "pmc": pmc}
+        if pmc["traffic_bytes_per_launch"] and roofline["avg_launch_ms"] > 0:
+            # the counters' bytes per launch of the same build and batch size (one lane, like this pass) over this pass's launch time
+            g = pmc["traffic_bytes_per_launch"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+            roofline["hbm_by_counters"] = {"GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_launch": pmc["traffic_bytes_per_launch"],
+                                           "source": pmc["traffic_source"]}
         if pmc["valu"] and pmc["valu"]["frac"] > roofline["frac"]:
             roofline["bound"] = "valu"   # the vector-issue share of the same kernel (PMC pass of this build) exceeds its HBM share
 

@@ -986,7 +986,7 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         // segments (the pixels over the scene) repeat with a power-of-two period from sample to sample and their addresses
         // fall on a fraction of the HBM channels: measured 45.5 against 28.3 ms for 2^18 pixels x 54 spp.  One more chunk
         // per segment breaks the period.  (PATHTRACE_HIP_SEG fixes the size for measurements.)
-        static const bool seg_forced = getenv("PATHTRACE_HIP_SEG") != nullptr;
+        const bool seg_forced = getenv("PATHTRACE_HIP_SEG") != nullptr;
         b.seg_cap = (npix % 65536 == 0 && !seg_forced) ? c->seg_cap + 256 : c->seg_cap;
         b.n_paths = npix * ns;
         b.n_seg = (int)((b.n_paths + b.seg_cap - 1) / b.seg_cap);

@@ -165,6 +165,28 @@ def test_batching_tiling_and_sample_ranges_do_not_change_the_image(oracle):
     r.close()
 
 
+@pytest.mark.parametrize("max_paths", [8192, 8192 + 77, 3 * 4096 - 1])
+def test_multi_rect_batches_at_the_allocation_edge(max_paths, monkeypatch):
+    # the index range behind round 2's abort.  Segments of 256 slots and a slot budget that the batches
+    # fill to the last record (8192 = both tiles x 1 sample = 32 full segments), one past a segment boundary, and one
+    # short of it: the last (merged) segment of every bounce ends at, or hangs over, the end of the streams.  Same bits
+    # as the whole frame in one batch with the default segments.
+    scene, w, h, spp = "cornell_box", 128, 64, 5
+    whole, c0 = gpu_render(scene, w, h, spp)
+    monkeypatch.setenv("PATHTRACE_HIP_SEG", "256")
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, max_paths_in_flight=max_paths)
+    tiles = pt.spiral_tiles(w, h, 64, 64)
+    r.render_tiles_async(tiles[::-1], 0, spp)
+    assert np.array_equal(bits(whole), bits(r.framebuffer())) and r.counters() == c0
+    r.clear()
+    for t in tiles:
+        r.render_tiles_async([t], 0, 2)
+        r.render_tiles_async([t], 2, spp)
+    assert np.array_equal(bits(whole), bits(r.framebuffer())) and r.counters() == c0
+    r.close()
+
+
 def test_cost_balanced_tile_ownership(oracle):
     # the N > 1 scheduler on one GPU: per-tile costs measured through the C ABI equal the oracle's ray counts, the
     # ownership map derived from them is a partition, and the "ranks" rendered back to back give the one-GPU image
