@@ -93,10 +93,12 @@ def stream_bytes(kernel, d, light_samples, n_launches, pixels, generate_launches
 
 
 def launch_plan(my_pixels, total_spp):
-    """Samples per pixel of one wavefront launch: batches of at most MAX_BATCH_PATHS paths, and at least 2 x lanes of them
-    (three in flight fill the chip; with fewer the thin late bounces of the last batches run alone).  Independent of N."""
+    """Samples per pixel of one wavefront launch: as few batches as MAX_BATCH_PATHS paths each allow, and at least one per lane
+    (three in flight fill the chip).  Independent of N.  Measured with tools/plan_probe.py (profiles/r03d_launch_plans.jsonl):
+    for every N and K the fewest batches win -- a rank of N = 8 at K = 20 takes 19.2 ms in 3 batches, 20.8 in 6, 22.8 in 12 --
+    because every batch pays its thin late bounces (30 launches of a few hundred thousand paths) once."""
     spp_cap = max(1, MAX_BATCH_PATHS // max(my_pixels, 1))
-    want = -(-total_spp // int(os.environ.get("PT_BENCH_TARGET_BATCHES", str(2 * N_LANES))))
+    want = -(-total_spp // int(os.environ.get("PT_BENCH_TARGET_BATCHES", str(N_LANES))))
     if os.environ.get("PT_BENCH_GROUP"):   # measurement knob: steps per launch
         want = SPP_PER_STEP * int(os.environ["PT_BENCH_GROUP"])
     return max(1, min(spp_cap, want))

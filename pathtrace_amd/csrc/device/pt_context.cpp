@@ -55,6 +55,13 @@ static void set_err(const char *fmt, ...)
     } while (0)
 
 extern "C" const char *pt_last_error(void) { return g_err.c_str(); }
+// Segments stop merging at this many: every wave of k_shade reserves its output ranges with returning atomics on the output
+// segment's two counters, and with a handful of segments left (32 at bounce 9 of a 66 M-path batch) those serialise: k_shade's
+// launches of bounces 7 - 9 took 228 / 204 / 219 us, with 507 segments kept 174 / 132 / 108.
+// PATHTRACE_HIP_MERGE_MIN overrides it for measurements.
+#ifndef PT_MERGE_MIN_SEGMENTS
+#define PT_MERGE_MIN_SEGMENTS 512
+#endif
 void pth_set_error(const std::string &m) { g_err = m; }   // used by the host front end (pt_host.cpp)
 extern "C" int pt_abi_version(void) { return PT_ABI_VERSION; }
 extern "C" int pt_device_count(void)
@@ -922,7 +929,8 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
         // segments merge pairwise from one bounce to the next (pt_device.h DBatch) until one is left
         static const bool no_merge = getenv("PATHTRACE_HIP_NO_MERGE") != nullptr;
-        if (bb.n_seg > 1 && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
+        static const int merge_min = getenv("PATHTRACE_HIP_MERGE_MIN") ? atoi(getenv("PATHTRACE_HIP_MERGE_MIN")) : PT_MERGE_MIN_SEGMENTS;
+        if (bb.n_seg > 1 && bb.n_seg > merge_min && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
         else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
         bb.perm = seg_perm(bb.n_seg); bb.perm_out = seg_perm(bb.n_seg_out);
         { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm, spec); }
