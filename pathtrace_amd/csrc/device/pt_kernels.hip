@@ -75,6 +75,9 @@ namespace ptd {
 #define PT_CONNECT_PREFETCH 1   // k_connect: 1 = the radiance is requested as soon as the slot is known; 2 = and the next group's shadow
                                 // records before the current group is traced (12 more VGPRs at two rays per sweep); 0 = neither
 #endif
+#ifndef PT_SKIP_NOOP_RADIANCE
+#define PT_SKIP_NOOP_RADIANCE 1   // radiance updates that cannot change a bit are not performed (0: the A/B)
+#endif
 #ifndef PT_FUSE_GENERATE
 #define PT_FUSE_GENERATE 1   // bounce 0 forms its camera rays itself, no k_generate launch (0: k_generate writes them, as before)
 #endif
@@ -1731,7 +1734,11 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 }
                 const v3 add = vmul(beta, bg);
                 if (B0) rad0 = make_float4(rad0.x + add.x, rad0.y + add.y, rad0.z + add.z, 0.0f);
-                else {
+                else if (!PT_SKIP_NOOP_RADIANCE || !(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f)) {
+                    // A black background (the Cornell scenes) adds +-0: the sum keeps its bits -- x + (+-0) = x for every x but -0,
+                    // and a radiance component is never -0 (it starts as +0, and a float sum is -0 only when both terms are) --
+                    // so the random 16-byte read and write of the slot (a 64-byte sector each way in HBM; a third of the paths that
+                    // end at bounce >= 1 end here) are skipped.  NaN and inf * 0 are not equal to 0 and take the addition.
                     const float4 rad = st.radiance[slot];
                     st.radiance[slot] = make_float4(rad.x + add.x, rad.y + add.y, rad.z + add.z, 0.0f);
                 }
@@ -2146,7 +2153,9 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
 #endif
             v3 r = vadd(V(rad.x, rad.y, rad.z), vdiv_count(lc, n_samples));   // integrator.h:268
             if (slotw < 0) { const float4 pe = st.pending[slot]; r = vadd(r, V(pe.x, pe.y, pe.z)); }
-            st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
+            // every shadow ray blocked (or every coefficient +-0): the sum has the bits it had, the store is skipped
+            if (!PT_SKIP_NOOP_RADIANCE || __float_as_int(r.x) != __float_as_int(rad.x) || __float_as_int(r.y) != __float_as_int(rad.y) || __float_as_int(r.z) != __float_as_int(rad.z))
+                st.radiance[slot] = make_float4(r.x, r.y, r.z, 0.0f);
         }
     }
     if (threadIdx.x == 0 && n_rays) {
