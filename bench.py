@@ -507,7 +507,7 @@ def main():
                        "framebuffer_sum": fb_sum,
                        "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce"),
                        "partition_setup_ms": round(setup_ms, 1),
-                       "sweep": "per-scene build of k_extend (hiprtc at pt_create), generic k_connect" if spec_state == 1 else "generic kernels",
+                       "sweep": ("per-scene build of k_extend and k_connect (hiprtc at pt_create)" if os.environ.get("PATHTRACE_HIP_SPEC_CONNECT", "1")[:1] != "0" else "per-scene build of k_extend (hiprtc at pt_create), generic k_connect") if spec_state == 1 else "generic kernels",
                        "knobs": knobs},
             "roofline": roofline,
             "scaling_proxy": proxy,

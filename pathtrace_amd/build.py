@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpathtrace_hip.so")
+SPEC_CC = os.path.join(LIB_DIR, "pt_spec_cc")   # the per-scene build's compiler process (csrc/device/pt_spec_cc.cpp), beside the library
 SOURCES = [
     os.path.join(CSRC, "device", "pt_kernels.hip"),
     os.path.join(CSRC, "device", "pt_context.cpp"),
@@ -24,14 +25,19 @@ HEADERS = [
     os.path.join(CSRC, "device", "pt_device.h"),
     os.path.join(CSRC, "device", "pt_fdiv.h"),
     os.path.join(CSRC, "device", "pt_spec.h"),
+    os.path.join(CSRC, "device", "pt_rtc_core.h"),
+    os.path.join(CSRC, "device", "pt_spec_cc.cpp"),
     os.path.join(CSRC, "host", "json_min.h"),
     os.path.join(HERE, "..", "include", "pathtrace_hip.h"),
 ]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 mul/add into v_pk_*_f32, whose SGPR operands must be
 # aligned pairs -- every packed op then costs two s_mov on the (single per CU) scalar unit and extra VGPRs.
+# PT_ROCM_LIB_DIR: where this toolchain's libhiprtc / libamd_comgr live -- the per-scene build (pt_spec.cpp) loads THEM, not
+# whatever ROCm the host process may carry (a PyTorch wheel bundles its own, older, compiler)
+ROCM_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function", "-ldl"]
+         "-Wall", "-Wno-unused-function", "-ldl", f'-DPT_ROCM_LIB_DIR="{ROCM_LIB_DIR}"']
 
 
 def embed_sources(defs=()) -> None:
@@ -61,7 +67,7 @@ def embed_sources(defs=()) -> None:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SPEC_CC):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS + [os.path.abspath(__file__)])
@@ -78,6 +84,12 @@ def build(force: bool = False, verbose: bool = False, defs=(), out: str = None) 
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    # the helper is plain host C++ (it loads hiprtc itself): one file, no HIP
+    cc = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-Wall", f'-DPT_ROCM_LIB_DIR="{ROCM_LIB_DIR}"',
+          os.path.join(CSRC, "device", "pt_spec_cc.cpp"), "-o", SPEC_CC, "-ldl"]
+    if verbose:
+        print(" ".join(cc), flush=True)
+    subprocess.run(cc, check=True)
     return target
 
 

@@ -2272,11 +2272,10 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     int nr = (L % 2 == 0) ? 2 : 1;
     if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     if (S.walk) nr = 1;   // the walk takes its rays one at a time
-    // The module's k_connect is the same ISA as a statically linked build of the specialised kernel, yet launched through
-    // the module API it runs 1.4 x slower than that build (20.4 against 13.9 ms per 64 spp; k_extend 4.9 against 4.7), for a
-    // reason not found; the statically linked gain is 3 % of this kernel anyway (two rays per sweep already
-    // share the op fetch).  So shadow rays keep the generic kernel unless PATHTRACE_HIP_SPEC_CONNECT=1 asks for the module's.
-    const bool spec_connect = getenv("PATHTRACE_HIP_SPEC_CONNECT") != nullptr;   // read per launch: the tests switch it
+    // The module's k_connect (straight-line sweep, 5 waves per SIMD) is worth 3 - 4 % of this kernel -- two rays per sweep already
+    // share the op fetch of the generic loop.  PATHTRACE_HIP_SPEC_CONNECT=0 keeps shadow rays on the generic kernel (the A/B).
+    const char *sc_env = getenv("PATHTRACE_HIP_SPEC_CONNECT");   // read per launch: the tests switch it
+    const bool spec_connect = !(sc_env && sc_env[0] == '0');
     if (!spec_connect) spec = nullptr;
     if (spec && !S.walk && L % spec_connect_nr(spec) == 0) nr = spec_connect_nr(spec);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);

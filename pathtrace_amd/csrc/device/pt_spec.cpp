@@ -13,6 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   // dlmopen
+#endif
 #include <dlfcn.h>
 
 #include <atomic>
@@ -24,10 +27,21 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
+#include <errno.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "pt_rtc_core.h"
 #include "pt_spec.h"
+extern char **environ;
+#ifndef PT_ROCM_LIB_DIR
+#define PT_ROCM_LIB_DIR "/opt/rocm/lib"
+#endif
 
 namespace ptd {
 
@@ -47,38 +61,8 @@ static const char *const kBuildFlags[] = {
 };
 
 namespace {
-// ---- hiprtc through dlopen ----
-struct Rtc {
-    void *lib = nullptr;
-    int (*CreateProgram)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
-    int (*CompileProgram)(void *, int, const char **) = nullptr;
-    int (*AddNameExpression)(void *, const char *) = nullptr;
-    int (*GetLoweredName)(void *, const char *, const char **) = nullptr;
-    int (*GetCodeSize)(void *, size_t *) = nullptr;
-    int (*GetCode)(void *, char *) = nullptr;
-    int (*GetProgramLogSize)(void *, size_t *) = nullptr;
-    int (*GetProgramLog)(void *, char *) = nullptr;
-    int (*DestroyProgram)(void **) = nullptr;
-    bool load()
-    {
-        if (lib) return true;
-        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (lib) break;
-        }
-        if (!lib) return false;
-#define SYM(f, n) f = (decltype(f))dlsym(lib, n)
-        SYM(CreateProgram, "hiprtcCreateProgram"); SYM(CompileProgram, "hiprtcCompileProgram");
-        SYM(AddNameExpression, "hiprtcAddNameExpression"); SYM(GetLoweredName, "hiprtcGetLoweredName");
-        SYM(GetCodeSize, "hiprtcGetCodeSize"); SYM(GetCode, "hiprtcGetCode");
-        SYM(GetProgramLogSize, "hiprtcGetProgramLogSize"); SYM(GetProgramLog, "hiprtcGetProgramLog");
-        SYM(DestroyProgram, "hiprtcDestroyProgram");
-#undef SYM
-        return CreateProgram && CompileProgram && AddNameExpression && GetLoweredName && GetCodeSize && GetCode && DestroyProgram;
-    }
-};
-Rtc g_rtc;
-std::mutex g_rtc_mutex;   // one compile at a time (comgr is heavy, and the cache below is filled under it)
+ptrtc::Rtc g_rtc;          // the in-process compiler (fallback)
+std::mutex g_rtc_mutex;    // one compile at a time (comgr is heavy, and the cache below is filled under it)
 
 struct CodeObject {
     std::vector<char> code;
@@ -87,11 +71,50 @@ struct CodeObject {
 };
 std::map<std::string, std::shared_ptr<CodeObject>> g_cache;   // key: table text + flags
 
-uint64_t fnv1a(const std::string &s)
+// The directory this library was loaded from: its compile helper (pt_spec_cc) sits beside it.
+std::string library_dir()
 {
-    uint64_t h = 1469598103934665603ull;
-    for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; }
-    return h;
+    Dl_info info;
+    if (!dladdr((const void *)&library_dir, &info) || !info.dli_fname) return "";
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+// The compilation in a process of its own.  Why: the compiler must be the toolchain this library was built with.  A host
+// process may already hold ANOTHER ROCm's libhiprtc / libamd_comgr under the same sonames -- PyTorch wheels bundle theirs
+// (roc-7.0 / LLVM 20 in this image, against /opt/rocm's roc-7.2 / LLVM 22) -- and dlopen("libhiprtc.so"), and hiprtc's own
+// dlopen of comgr, then return THOSE: the module was being built by the older compiler, whose code for these kernels is
+// different (generic k_connect: 24 spilled VGPRs and 76 B of scratch against none; 25.6 against 13.0 ms per 64 spp).  A child
+// process holds nothing but what it loads itself.  (A second link-map namespace, dlmopen, does the same in-process and was
+// tried first: it crashed after some twenty compilations beside a live HIP runtime.)  The helper never touches the GPU.
+// Returns false when the helper could not be run at all (missing file, spawn failure): the caller then compiles in-process.
+bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &why)
+{
+    const char *forced = getenv("PATHTRACE_HIP_SPEC_CC");
+    const std::string exe = forced ? std::string(forced) : library_dir() + "/pt_spec_cc";
+    if (access(exe.c_str(), X_OK) != 0) { why = exe + " is not there"; return false; }
+    const char *tmp = getenv("TMPDIR");
+    char req[512], res[512];
+    snprintf(req, sizeof req, "%s/pt_spec_req_XXXXXX", tmp && *tmp ? tmp : "/tmp");
+    snprintf(res, sizeof res, "%s/pt_spec_res_XXXXXX", tmp && *tmp ? tmp : "/tmp");
+    const int fq = mkstemp(req), fr = mkstemp(res);
+    if (fq >= 0) close(fq);
+    if (fr >= 0) close(fr);
+    bool ran = false;
+    if (fq >= 0 && fr >= 0 && ptrtc::write_request(req, q)) {
+        char *const argv[] = {(char *)exe.c_str(), req, res, nullptr};
+        pid_t pid = 0;
+        if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) == 0) {
+            int status = 0;
+            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+            if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && ptrtc::read_result(res, r)) ran = true;
+            else why = "pt_spec_cc ended abnormally";
+        } else why = "posix_spawn(pt_spec_cc) failed";
+    } else why = "no temporary file for the compile request";
+    if (fq >= 0) unlink(req);
+    if (fr >= 0) unlink(res);
+    return ran;
 }
 }  // namespace
 
@@ -99,57 +122,46 @@ uint64_t fnv1a(const std::string &s)
 static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_all, bool textured, int connect_nr, std::string &log)
 {
     char flags[256];
-    snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, getenv("PATHTRACE_HIP_SPEC_WAVES") ? getenv("PATHTRACE_HIP_SPEC_WAVES") : "5");
+    snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, getenv("PATHTRACE_HIP_SPEC_WAVES") ? getenv("PATHTRACE_HIP_SPEC_WAVES") : "5",
+             getenv("PATHTRACE_HIP_SPEC_GENERIC") ? 1 : 0);
     const std::string key = table + flags;
     std::lock_guard<std::mutex> lock(g_rtc_mutex);
     if (getenv("PATHTRACE_HIP_SPEC_BREAK")) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
     auto hit = g_cache.find(key);
     if (hit != g_cache.end()) return hit->second;
-    if (!g_rtc.load()) { log = "libhiprtc.so could not be loaded"; return nullptr; }
-    const std::string top = "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
-    const char *headers[] = {kSrcKernels, kSrcDevice, kSrcFdiv, table.c_str()};
-    const char *names[] = {"pt_kernels.hip", "pt_device.h", "pt_fdiv.h", "pt_spec_table.h"};
-    void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, top.c_str(), "pt_spec_top.hip", 4, headers, names) != 0) { log = "hiprtcCreateProgram failed"; return nullptr; }
+    ptrtc::Request q;
+    // PATHTRACE_HIP_SPEC_GENERIC (measurement): the module holds the GENERIC kernels -- the library's own code through the module path
+    q.top = getenv("PATHTRACE_HIP_SPEC_GENERIC") ? "#define PT_SPEC_BUILD 1\n#include \"pt_kernels.hip\"\n"
+                                                 : "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
+    q.top_name = "pt_spec_top.hip";
+    q.headers = {{"pt_kernels.hip", kSrcKernels}, {"pt_device.h", kSrcDevice}, {"pt_fdiv.h", kSrcFdiv}, {"pt_spec_table.h", table}};
+    const char *ga = geom_all ? "true" : "false", *tex = textured ? "true" : "false";
+    char e[128];
+    snprintf(e, sizeof e, "ptd::k_extend<%s, false, false>", ga); q.exprs.push_back(e);
+    snprintf(e, sizeof e, "ptd::k_extend<%s, false, true>", ga); q.exprs.push_back(e);
+    snprintf(e, sizeof e, "ptd::k_connect<%d, %s, %s, false>", connect_nr, tex, ga); q.exprs.push_back(e);
+    for (int nr : {1, 2, 4}) { snprintf(e, sizeof e, "ptd::k_trace<%d, %s, false>", nr, ga); q.exprs.push_back(e); }
+    // the product's flags (pathtrace_amd/build.py): no FMA contraction, IEEE division and square root; the specialised k_connect
+    // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17) and without the early radiance request, which at this
+    // register budget is spilled the moment it arrives
+    const char *waves = "-DPT_CONNECT_WAVES=5";
+    if (const char *w = getenv("PATHTRACE_HIP_SPEC_WAVES")) { if (!strcmp(w, "4")) waves = "-DPT_CONNECT_WAVES=4"; else if (!strcmp(w, "6")) waves = "-DPT_CONNECT_WAVES=6"; }
+    q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    if (!getenv("PATHTRACE_HIP_SPEC_GENERIC")) { q.opts.push_back(waves); q.opts.push_back(getenv("PATHTRACE_HIP_SPEC_PF1") ? "-DPT_CONNECT_PREFETCH=1" : "-DPT_CONNECT_PREFETCH=0"); }
+    for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
+    ptrtc::Result r;
+    std::string why;
+    // PATHTRACE_HIP_RTC_SHARED=1 (the A/B): compile in-process with whatever libhiprtc the process resolves
+    if (getenv("PATHTRACE_HIP_RTC_SHARED") || !compile_in_child(q, r, why)) {
+        if (!g_rtc.load({"libhiprtc.so", "libhiprtc.so.7", PT_ROCM_LIB_DIR "/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"})) { log = "no compiler: " + (why.empty() ? std::string() : why + "; ") + "libhiprtc.so could not be loaded"; return nullptr; }
+        ptrtc::run(g_rtc, q, r);
+    }
+    if (r.status != 0 || r.lowered.size() != 6 || r.code.empty()) { log = r.log.empty() ? "the per-scene build produced no code object" : r.log; return nullptr; }
     auto obj = std::make_shared<CodeObject>();
     obj->connect_nr = connect_nr;
-    const char *ga = geom_all ? "true" : "false", *tex = textured ? "true" : "false";
-    char e_ext[2][128], e_con[128], e_tr[3][128];
-    snprintf(e_ext[0], sizeof e_ext[0], "ptd::k_extend<%s, false, false>", ga);
-    snprintf(e_ext[1], sizeof e_ext[1], "ptd::k_extend<%s, false, true>", ga);
-    snprintf(e_con, sizeof e_con, "ptd::k_connect<%d, %s, %s, false>", connect_nr, tex, ga);
-    const int trs[3] = {1, 2, 4};
-    for (int i = 0; i < 3; i++) snprintf(e_tr[i], sizeof e_tr[i], "ptd::k_trace<%d, %s, false>", trs[i], ga);
-    bool ok = g_rtc.AddNameExpression(prog, e_ext[0]) == 0 && g_rtc.AddNameExpression(prog, e_ext[1]) == 0 && g_rtc.AddNameExpression(prog, e_con) == 0;
-    for (int i = 0; i < 3; i++) ok = ok && g_rtc.AddNameExpression(prog, e_tr[i]) == 0;
-    // the product's flags (pathtrace_amd/build.py): no FMA contraction, IEEE division and square root; the specialised k_connect
-    // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17, measured +10 % instead of -4 %) and without the early
-    // radiance request, which at this register budget is spilled the moment it arrives (k_connect 20.5 against 14.3 ms)
-    const char *waves = "-DPT_CONNECT_WAVES=5";
-    if (const char *e = getenv("PATHTRACE_HIP_SPEC_WAVES")) { if (!strcmp(e, "4")) waves = "-DPT_CONNECT_WAVES=4"; else if (!strcmp(e, "6")) waves = "-DPT_CONNECT_WAVES=6"; }
-    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", waves, "-DPT_CONNECT_PREFETCH=0"};
-    for (const char *const *f = kBuildFlags; *f; f++) opts.push_back(*f);
-    const int rc = ok ? g_rtc.CompileProgram(prog, (int)opts.size(), opts.data()) : -1;
-    if (rc != 0) {
-        size_t n = 0;
-        if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) { log.resize(n); g_rtc.GetProgramLog(prog, &log[0]); }
-        else log = "hiprtcCompileProgram failed";
-        g_rtc.DestroyProgram(&prog);
-        return nullptr;
-    }
-    const char *lowered = nullptr;
-    ok = g_rtc.GetLoweredName(prog, e_ext[0], &lowered) == 0 && lowered;
-    if (ok) obj->name_extend[0] = lowered;
-    ok = ok && g_rtc.GetLoweredName(prog, e_ext[1], &lowered) == 0 && lowered;
-    if (ok) obj->name_extend[1] = lowered;
-    ok = ok && g_rtc.GetLoweredName(prog, e_con, &lowered) == 0 && lowered;
-    if (ok) obj->name_connect = lowered;
-    for (int i = 0; i < 3 && ok; i++) { ok = g_rtc.GetLoweredName(prog, e_tr[i], &lowered) == 0 && lowered; if (ok) obj->name_trace[i] = lowered; }
-    size_t sz = 0;
-    ok = ok && g_rtc.GetCodeSize(prog, &sz) == 0 && sz > 0;
-    if (ok) { obj->code.resize(sz); ok = g_rtc.GetCode(prog, obj->code.data()) == 0; }
-    g_rtc.DestroyProgram(&prog);
-    if (!ok) { log = "hiprtc: no code object / lowered names"; return nullptr; }
+    obj->name_extend[0] = r.lowered[0]; obj->name_extend[1] = r.lowered[1]; obj->name_connect = r.lowered[2];
+    for (int i = 0; i < 3; i++) obj->name_trace[i] = r.lowered[3 + i];
+    obj->code = std::move(r.code);
     if (const char *dump = getenv("PATHTRACE_HIP_SPEC_DUMP")) {   // the code object, for llvm-objdump / tools/isa_stats.py
         if (FILE *fh = fopen(dump, "wb")) { fwrite(obj->code.data(), 1, obj->code.size(), fh); fclose(fh); }
     }
@@ -235,7 +247,21 @@ void spec_destroy(SpecJob *j)
     delete j;
 }
 
+static int launch_(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args);
 static int launch(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args)
+{
+    static const bool timed = getenv("PATHTRACE_HIP_SPEC_TIME") != nullptr;   // measurement: host time spent inside the module launch call
+    if (!timed) return launch_(f, grid, lds, s, args);
+    static double total_us = 0.0, max_us = 0.0;
+    static long calls = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = launch_(f, grid, lds, s, args);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    total_us += us; calls++; if (us > max_us) max_us = us;
+    if (calls % 200 == 0) fprintf(stderr, "[pt spec] %ld module launches, mean %.1f us, max %.1f us inside the call\n", calls, total_us / calls, max_us);
+    return rc;
+}
+static int launch_(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args)
 {
     static const char *how = getenv("PATHTRACE_HIP_SPEC_LAUNCH");
     if (how && !strcmp(how, "ext"))

@@ -14,12 +14,12 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["extend", "extend+connect"])
 def spec_sync(monkeypatch, request):
-    # by default the module serves k_extend and k_trace; PATHTRACE_HIP_SPEC_CONNECT=1 adds its k_connect
+    # the module serves k_extend, k_connect and k_trace; PATHTRACE_HIP_SPEC_CONNECT=0 leaves shadow rays on the generic k_connect
     monkeypatch.setenv("PATHTRACE_HIP_SPEC", "sync")
     if request.param == "extend+connect":
-        monkeypatch.setenv("PATHTRACE_HIP_SPEC_CONNECT", "1")
-    else:
         monkeypatch.delenv("PATHTRACE_HIP_SPEC_CONNECT", raising=False)
+    else:
+        monkeypatch.setenv("PATHTRACE_HIP_SPEC_CONNECT", "0")
 
 
 @pytest.mark.parametrize("scene", ALL_SCENES)

@@ -39,3 +39,26 @@ def test_a_broken_build_reports_instead_of_raising_into_the_render(monkeypatch):
     sc = pt.Scene(scene_path("three_orbs"), 64, 64)
     with pytest.raises(pt.PathtraceError, match="fails on purpose"):
         pt.spec_build_check(sc, 4)
+
+
+def test_the_module_is_built_by_this_toolchain_whatever_the_process_holds(tmp_path, monkeypatch):
+    # A PyTorch wheel brings its own libhiprtc / libamd_comgr (an older LLVM) under the sonames of /opt/rocm's: with torch
+    # imported, an in-process dlopen("libhiprtc.so") compiled the module with THAT compiler (24 spilled VGPRs in the generic
+    # k_connect against none).  The build therefore runs in a helper process (pathtrace_amd/lib/pt_spec_cc): the code object's
+    # producer string must be hipcc's.
+    import os
+    import subprocess
+    import torch  # noqa: F401  (the point: its libraries are in the process)
+    from pathtrace_amd import build as ptb
+
+    assert os.access(ptb.SPEC_CC, os.X_OK)
+    out = tmp_path / "m.co"
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_DUMP", str(out))
+    sc = pt.Scene(scene_path("light_test"), 48, 27)      # a table no other test compiled: nothing comes from the process cache
+    assert pt.spec_build_check(sc, 7) > 20000
+    blob = out.read_bytes()
+    hipcc = subprocess.run([ptb.HIPCC, "--version"], capture_output=True, text=True).stdout
+    version = re.search(r"clang version (\S+)", hipcc).group(1)
+    build_id = re.search(r"roc-[0-9.]+ \d+ [0-9a-f]+", hipcc)
+    assert ("clang version " + version).encode() in blob
+    assert build_id is None or build_id.group(0).encode() in blob
