@@ -32,6 +32,7 @@
 #include <vector>
 
 #include <errno.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -106,8 +107,12 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
         char *const argv[] = {(char *)exe.c_str(), req, res, nullptr};
         pid_t pid = 0;
         if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) == 0) {
-            int status = 0;
-            while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+            int status = 0, w;
+            while ((w = waitpid(pid, &status, 0)) < 0 && errno == EINTR) {}
+            if (w < 0) {   // a host that ignores SIGCHLD reaps children itself (ECHILD): wait until the process is gone
+                while (kill(pid, 0) == 0) usleep(20000);
+                status = 0;
+            }
             if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && ptrtc::read_result(res, r)) ran = true;
             else why = "pt_spec_cc ended abnormally";
         } else why = "posix_spawn(pt_spec_cc) failed";
@@ -124,7 +129,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     char flags[256];
     snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, getenv("PATHTRACE_HIP_SPEC_WAVES") ? getenv("PATHTRACE_HIP_SPEC_WAVES") : "5",
              getenv("PATHTRACE_HIP_SPEC_GENERIC") ? 1 : 0);
-    const std::string key = table + flags;
+    const std::string key = table + flags + (getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "");
     std::lock_guard<std::mutex> lock(g_rtc_mutex);
     if (getenv("PATHTRACE_HIP_SPEC_BREAK")) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
     auto hit = g_cache.find(key);
@@ -149,6 +154,13 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     if (!getenv("PATHTRACE_HIP_SPEC_GENERIC")) { q.opts.push_back(waves); q.opts.push_back(getenv("PATHTRACE_HIP_SPEC_PF1") ? "-DPT_CONNECT_PREFETCH=1" : "-DPT_CONNECT_PREFETCH=0"); }
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
+    std::string extra = getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "";   // measurement: more compiler options, space separated
+    for (size_t i = 0; i < extra.size();) {
+        const size_t j = extra.find(' ', i);
+        if (j != i) q.opts.push_back(extra.substr(i, j == std::string::npos ? j : j - i));
+        if (j == std::string::npos) break;
+        i = j + 1;
+    }
     ptrtc::Result r;
     std::string why;
     // PATHTRACE_HIP_RTC_SHARED=1 (the A/B): compile in-process with whatever libhiprtc the process resolves

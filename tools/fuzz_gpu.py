@@ -7,7 +7,8 @@ For every seed: a generated scene (tests/scene_gen.py; varying instance counts s
 program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_NO_FASTDIV=1 on every 5th seed; light_samples
 4, 1, 2, 7, 3 by seed so that k_shade's staged and unstaged instantiations both run; the chunk sort forced on for every 3rd
 seed and the staging forced off for every 7th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
-bits and all nine path counters must agree."""
+bits and all nine path counters must agree.  With PATHTRACE_HIP_SPEC=sync in the environment every scene is rendered by its own
+build of the traversal kernels (counted as "per_scene_build")."""
 import json
 import os
 import sys
@@ -53,6 +54,8 @@ def main():
             modes.setdefault("refused", 0)
             modes["refused"] += 1
             continue
+        if r.spec_status() == 1:   # PATHTRACE_HIP_SPEC=sync: the scene's own build of k_extend / k_connect renders it
+            modes["per_scene_build"] = modes.get("per_scene_build", 0) + 1
         g = r.render(4)
         gc = r.counters()
         r.close()
