@@ -54,7 +54,8 @@ def test_the_module_is_built_by_this_toolchain_whatever_the_process_holds(tmp_pa
     assert os.access(ptb.SPEC_CC, os.X_OK)
     out = tmp_path / "m.co"
     monkeypatch.setenv("PATHTRACE_HIP_SPEC_DUMP", str(out))
-    sc = pt.Scene(scene_path("light_test"), 48, 27)      # a table no other test compiled: nothing comes from the process cache
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_TOOLCHAIN=1")   # a key nothing has cached: this build runs now
+    sc = pt.Scene(scene_path("light_test"), 48, 27)
     assert pt.spec_build_check(sc, 7) > 20000
     blob = out.read_bytes()
     hipcc = subprocess.run([ptb.HIPCC, "--version"], capture_output=True, text=True).stdout
@@ -62,3 +63,13 @@ def test_the_module_is_built_by_this_toolchain_whatever_the_process_holds(tmp_pa
     build_id = re.search(r"roc-[0-9.]+ \d+ [0-9a-f]+", hipcc)
     assert ("clang version " + version).encode() in blob
     assert build_id is None or build_id.group(0).encode() in blob
+
+
+@pytest.mark.parametrize("helper", ["/nonexistent/pt_spec_cc", "/bin/false"])
+def test_without_a_working_helper_the_build_runs_in_process(helper, monkeypatch):
+    # the helper process is the preferred compiler, not a requirement: a missing file or one that ends without a result
+    # leaves the in-process hiprtc (and after that, on the GPU, the generic kernels)
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_CC", helper)
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_NO_HELPER_%d=1" % len(helper))   # a key nothing has cached
+    sc = pt.Scene(scene_path("three_orbs"), 40, 30)
+    assert pt.spec_build_check(sc, 6) > 20000
