@@ -5,8 +5,9 @@
 // of the two ran.  The module holds k_extend, k_connect and k_trace for this scene; everything else (and every scene
 // the build cannot serve) runs the generic kernels of the library.
 //
-//  * hiprtc is loaded on demand (dlopen): a machine without it, a compile error or PATHTRACE_HIP_SPEC=off leave the
-//    generic kernels in place, silently -- pt_spec_status tells.
+//  * The compilation runs in a helper process (pt_spec_cc beside the library, see compile_in_child) that loads this
+//    toolchain's hiprtc; without the helper, hiprtc is loaded in-process (dlopen).  A machine without either, a compile
+//    error or PATHTRACE_HIP_SPEC=off leave the generic kernels in place, silently -- pt_spec_status tells.
 //  * The build runs on a thread of its own (PATHTRACE_HIP_SPEC=async, the default): pt_create returns at once, launches
 //    switch to the module when it is ready.  PATHTRACE_HIP_SPEC=sync builds inside pt_create; pt_spec_wait blocks.
 //  * Code objects are cached per process by the hash of (table, flags): a second context of the same scene builds nothing.
