@@ -108,13 +108,19 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
         char *const argv[] = {(char *)exe.c_str(), req, res, nullptr};
         pid_t pid = 0;
         if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) == 0) {
-            int status = 0, w;
-            while ((w = waitpid(pid, &status, 0)) < 0 && errno == EINTR) {}
-            if (w < 0) {   // a host that ignores SIGCHLD reaps children itself (ECHILD): wait until the process is gone
-                while (kill(pid, 0) == 0) usleep(20000);
-                status = 0;
+            // wait for it, at most two minutes (a compilation takes 1.5 - 3 s): a helper that hangs is killed, not waited for
+            int status = 0, w = 0;
+            bool gone = false;
+            for (int tick = 0; tick < 6000 && !gone; tick++) {
+                w = waitpid(pid, &status, WNOHANG);
+                if (w == pid) gone = true;
+                else if (w < 0 && errno != EINTR) {   // a host that ignores SIGCHLD reaps children itself (ECHILD): watch the pid
+                    if (kill(pid, 0) != 0) { gone = true; status = 0; }
+                    else usleep(20000);
+                } else usleep(20000);
             }
-            if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && ptrtc::read_result(res, r)) ran = true;
+            if (!gone) { kill(pid, SIGKILL); while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} why = "pt_spec_cc did not finish in two minutes"; }
+            else if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && ptrtc::read_result(res, r)) ran = true;
             else why = "pt_spec_cc ended abnormally";
         } else why = "posix_spawn(pt_spec_cc) failed";
     } else why = "no temporary file for the compile request";
