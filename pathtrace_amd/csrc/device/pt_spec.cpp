@@ -136,7 +136,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     char flags[256];
     snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, getenv("PATHTRACE_HIP_SPEC_WAVES") ? getenv("PATHTRACE_HIP_SPEC_WAVES") : "5",
              getenv("PATHTRACE_HIP_SPEC_GENERIC") ? 1 : 0);
-    const std::string key = table + flags + (getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "");
+    const std::string key = table + flags + (getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "") + (getenv("PATHTRACE_HIP_SPEC_PF") ? getenv("PATHTRACE_HIP_SPEC_PF") : "");
     std::lock_guard<std::mutex> lock(g_rtc_mutex);
     if (getenv("PATHTRACE_HIP_SPEC_BREAK")) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
     auto hit = g_cache.find(key);
@@ -159,7 +159,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     const char *waves = "-DPT_CONNECT_WAVES=5";
     if (const char *w = getenv("PATHTRACE_HIP_SPEC_WAVES")) { if (!strcmp(w, "4")) waves = "-DPT_CONNECT_WAVES=4"; else if (!strcmp(w, "6")) waves = "-DPT_CONNECT_WAVES=6"; }
     q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
-    if (!getenv("PATHTRACE_HIP_SPEC_GENERIC")) { q.opts.push_back(waves); q.opts.push_back(getenv("PATHTRACE_HIP_SPEC_PF1") ? "-DPT_CONNECT_PREFETCH=1" : "-DPT_CONNECT_PREFETCH=0"); }
+    if (!getenv("PATHTRACE_HIP_SPEC_GENERIC")) { q.opts.push_back(waves); const char *pf = getenv("PATHTRACE_HIP_SPEC_PF"); q.opts.push_back(pf && pf[0] == '1' ? "-DPT_CONNECT_PREFETCH=1" : (pf && pf[0] == '2' ? "-DPT_CONNECT_PREFETCH=2" : "-DPT_CONNECT_PREFETCH=0")); }
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
     std::string extra = getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "";   // measurement: more compiler options, space separated
     for (size_t i = 0; i < extra.size();) {
