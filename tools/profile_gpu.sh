@@ -3,6 +3,7 @@
 #   tools/profile_gpu.sh r03a [scene.json]
 #   1. default bench.py line (headline scene only)              -> gpurun_out/<tag>_bench_default.json
 #   2. rocprofv3 --kernel-trace --stats of the same command    -> gpurun_out/<tag>_kernel_stats.csv
+#   2b. the same with one batch in flight (PATHTRACE_HIP_LANES=1) -> gpurun_out/<tag>_kernel_stats_one_lane.csv
 #   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), one lane -> gpurun_out/<tag>_pmc_{fetch,write}/
 #   4. one --pmc pass of SQ instruction counters               -> gpurun_out/<tag>_pmc_insts/
 #   5. one --pmc pass of SQ wait-state counters, one lane      -> gpurun_out/<tag>_pmc_wait/
@@ -24,6 +25,9 @@ if [ -n "$SCENE" ]; then Q="$Q --scene $R/scenes/$SCENE"; fi
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -- python3 "$R/bench.py" $Q > "$OUT/${TAG}_prof.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/${TAG}_prof.log"; exit 1; }
 export PATHTRACE_HIP_LANES=1
 export PT_BENCH_GROUP=2   # 32 spp per launch: the batches of the headline run
+# 2b. the same kernel-trace statistics with ONE batch in flight: every launch alone on the chip, so the table's average duration of a
+#     kernel is the one bench.py's roofline block uses (its own one-lane pass)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof1" -- python3 "$R/bench.py" --steps 8 --warmup 1 $Q > "$OUT/${TAG}_prof1.log" 2>&1 || { echo "one-lane kernel-trace failed"; tail -5 "$OUT/${TAG}_prof1.log"; exit 1; }
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_pmc_fetch" -- python3 "$R/bench.py" --steps 4 --warmup 1 $Q > "$OUT/${TAG}_pmc_fetch.log" 2>&1 || { echo "pmc fetch failed"; tail -5 "$OUT/${TAG}_pmc_fetch.log"; exit 1; }
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_pmc_write" -- python3 "$R/bench.py" --steps 4 --warmup 1 $Q > "$OUT/${TAG}_pmc_write.log" 2>&1 || { echo "pmc write failed"; tail -5 "$OUT/${TAG}_pmc_write.log"; exit 1; }
 # 4. instruction counters (own pass, serialised dispatches)

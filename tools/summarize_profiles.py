@@ -133,6 +133,9 @@ def main():
     tag, d = sys.argv[1], sys.argv[2]
     out = os.path.join(d, "summary_" + tag)
     os.makedirs(out, exist_ok=True)
+    ks1 = find(os.path.join(d, tag + "_prof1"), "kernel_stats.csv")
+    if ks1:
+        shutil.copy(ks1, os.path.join(out, tag + "_kernel_stats_one_lane.csv"))
     ks = find(os.path.join(d, tag + "_prof"), "kernel_stats.csv")
     if ks:
         shutil.copy(ks, os.path.join(out, tag + "_kernel_stats.csv"))
