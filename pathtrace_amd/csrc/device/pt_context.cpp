@@ -798,7 +798,9 @@ extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config
         std::string table;
         if (!off && !c->S.walk && spec_header_text(scene, table) > 0) {
             const int L = c->cfg.light_samples;
-            c->spec = spec_start(table, c->S.geom_all != 0, c->S.textured != 0, (L % 2 == 0) ? 2 : 1, c->device, mode && !strcmp(mode, "sync"));
+            int spec_nr = (L % 2 == 0) ? 2 : 1;   // rays per sweep of the module's k_connect; PATHTRACE_HIP_SPEC_NR=4 for measurements
+            if (const char *e = getenv("PATHTRACE_HIP_SPEC_NR")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && L % v == 0) spec_nr = v; }
+            c->spec = spec_start(table, c->S.geom_all != 0, c->S.textured != 0, spec_nr, c->device, mode && !strcmp(mode, "sync"));
         }
         g_err.clear();   // spec_header_text leaves a message for scenes it does not serve: not an error of pt_create
     }
