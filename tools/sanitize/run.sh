@@ -4,6 +4,7 @@
 #      malformed inputs                                           -> load_scenes
 #   2. the PNG reader on 7500 mutated copies of assets/*.png      -> png_fuzz
 #   3. the oracle (CPU restatement) through its own test file     -> pytest with a sanitized libpt_oracle.so
+#   4. the per-scene build's compile helper (pt_spec_cc) and its file protocol -> rtc_roundtrip
 # The device entry points the front end refers to are stubbed.  Run from the repo root: bash tools/sanitize/run.sh
 set -e
 R=$(pwd)
@@ -30,4 +31,8 @@ cp oracle/libpt_oracle.so $W/libpt_oracle.orig.so
 trap 'cp $W/libpt_oracle.orig.so oracle/libpt_oracle.so; touch oracle/libpt_oracle.so' EXIT
 gcc -std=c11 -O1 -g -fPIC -shared -pthread -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -o oracle/libpt_oracle.so oracle/pt_oracle.c -lm
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python3 -m pytest tests/test_oracle_golden.py -x -q | tail -2
+# 4. the per-scene build's helper process and its request / result files
+g++ $FLAGS pathtrace_amd/csrc/device/pt_spec_cc.cpp -o $W/pt_spec_cc_asan -ldl
+g++ $FLAGS tools/sanitize/rtc_roundtrip.cpp -o $W/rtc_roundtrip -ldl
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 $W/rtc_roundtrip $W/pt_spec_cc_asan $W
 echo "sanitizers: clean"
