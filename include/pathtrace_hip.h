@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
@@ -198,8 +198,15 @@ int pt_spec_header(const pt_scene_desc *scene, char *buf, size_t cap);
  * blocks until the build has ended and returns the same.  The image is the same bit for bit either way. */
 int pt_spec_status(pt_ctx *ctx);
 int pt_spec_wait(pt_ctx *ctx);
+/* ABI v5.  Provenance of the module: one line of JSON -- {"status", "built_by": "helper" | "in-process", "rtc_lib": path of
+ * the libhiprtc that compiled, "producer": the code object's compiler string, "own_compiler": true iff that is the hipcc
+ * that built this library}.  A foreign compiler builds correct but measurably slower kernels; bench.py labels such a run.
+ * Returns the text length; buf receives it when cap > length. */
+int pt_spec_info(pt_ctx *ctx, char *buf, size_t cap);
 /* host-only check: compile the scene's module for gfx950 without a device; returns its code size, < 0 on failure */
 long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_samples);
+/* the same check, answering with pt_spec_info's line for the module it built (ABI v5); < 0 when the build failed */
+int pt_spec_build_info(const pt_scene_desc *scene, int32_t light_samples, char *buf, size_t cap);
 int pt_set_profiling(pt_ctx *ctx, int enabled);
 int pt_get_kernel_times(pt_ctx *ctx, pt_kernel_times *out);
 /* debug / parity: radiance of every camera sample of the LAST batch rendered (de_nan not applied):

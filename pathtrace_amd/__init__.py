@@ -101,7 +101,7 @@ class HostConfig(C.Structure):
 # every symbol include/pathtrace_hip.h declares
 EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
-           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header", "pt_spec_status", "pt_spec_wait", "pt_spec_build_check",
+           "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header", "pt_spec_status", "pt_spec_wait", "pt_spec_info", "pt_spec_build_check", "pt_spec_build_info",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
            "pt_multi_create", "pt_multi_destroy", "pt_multi_render_async", "pt_multi_poll", "pt_multi_wait",
            "pt_multi_read_framebuffer", "pt_multi_snapshot_framebuffer", "pt_multi_get_counters", "pt_multi_clear",
@@ -146,8 +146,10 @@ def lib():
     L.pt_spec_header.argtypes = [C.POINTER(SceneDesc), C.c_char_p, C.c_size_t]
     L.pt_spec_status.argtypes = [vp]
     L.pt_spec_wait.argtypes = [vp]
+    L.pt_spec_info.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.pt_spec_build_check.argtypes = [C.POINTER(SceneDesc), C.c_int32]
     L.pt_spec_build_check.restype = C.c_long
+    L.pt_spec_build_info.argtypes = [C.POINTER(SceneDesc), C.c_int32, C.c_char_p, C.c_size_t]
     L.pt_multi_get_device_counters.argtypes = [vp, C.c_int32, C.POINTER(Counters)]
     L.pt_multi_exchange_bytes.argtypes = [vp]
     L.pt_multi_exchange_bytes.restype = C.c_uint64
@@ -278,6 +280,17 @@ def spec_build_check(scene: "Scene", light_samples: int = 4) -> int:
     return n
 
 
+def spec_build_info(scene: "Scene", light_samples: int = 4) -> dict:
+    """The same build, answering with pt_spec_info's record: which compiler a context of this scene gets in this process."""
+    import json
+    n = lib().pt_spec_build_info(C.byref(scene.desc), light_samples, None, 0)
+    if n < 0:
+        raise PathtraceError(f"pt_spec_build_info: {last_error()}")
+    buf = C.create_string_buffer(n + 1)
+    lib().pt_spec_build_info(C.byref(scene.desc), light_samples, buf, n + 1)
+    return json.loads(buf.value.decode())
+
+
 def load_config(path: str = None, text: str = None) -> HostConfig:
     hc = HostConfig()
     if text is not None:
@@ -380,6 +393,17 @@ class Renderer:
     def spec_wait(self) -> int:
         """Block until the per-scene build has ended; 1 = the context launches the scene's own kernels, -1 = generic."""
         return lib().pt_spec_wait(self._h)
+
+    def spec_info(self) -> dict:
+        """Who compiled the module this context launches (pt_spec_info): built_by helper / in-process, the libhiprtc file,
+        the code object's producer string and whether that is the compiler the library was built with."""
+        import json
+        n = lib().pt_spec_info(self._h, None, 0)
+        if n < 0:
+            raise PathtraceError(f"pt_spec_info: {last_error()}")
+        buf = C.create_string_buffer(n + 1)
+        lib().pt_spec_info(self._h, buf, n + 1)
+        return json.loads(buf.value.decode())
 
     def set_profiling(self, on: bool):
         _check(lib().pt_set_profiling(self._h, int(on)), "pt_set_profiling")

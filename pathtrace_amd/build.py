@@ -35,7 +35,25 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # aligned pairs -- every packed op then costs two s_mov on the (single per CU) scalar unit and extra VGPRs.
 # PT_ROCM_LIB_DIR: where this toolchain's libhiprtc / libamd_comgr live -- the per-scene build (pt_spec.cpp) loads THEM, not
 # whatever ROCm the host process may carry (a PyTorch wheel bundles its own, older, compiler)
-ROCM_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
+# As hipcc was NAMED (normally /opt/rocm/lib, the symlink): the versioned directory behind it need not exist on the machine
+# that runs the library; pt_spec.cpp checks the directory at run time and falls back to /opt/rocm/lib.
+ROCM_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(HIPCC))), "lib")
+if not os.path.exists(os.path.join(ROCM_LIB_DIR, "libhiprtc.so")):
+    ROCM_LIB_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib")
+
+
+def hipcc_producer() -> str:
+    """'clang version X.Y.Z (repository build-id)' of the hipcc that builds the library: the text a code object's producer string must contain for
+    the per-scene module to count as built by this toolchain (pt_spec_info's own_compiler)."""
+    import re
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return ""
+    m = re.search(r"clang version [^\n\"\\]+", out)   # version and the build id in parentheses: "clang version 22.0.0git (... roc-7.2.0 ...)"
+    return m.group(0).strip() if m else ""
+
+
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function", "-ldl", f'-DPT_ROCM_LIB_DIR="{ROCM_LIB_DIR}"']
 
@@ -80,7 +98,7 @@ def build(force: bool = False, verbose: bool = False, defs=(), out: str = None) 
     os.makedirs(LIB_DIR, exist_ok=True)
     embed_sources(defs)
     target = os.path.join(LIB_DIR, out) if out else LIB
-    cmd = [HIPCC] + FLAGS + list(defs) + SOURCES + ["-o", target]
+    cmd = [HIPCC] + FLAGS + [f'-DPT_HIPCC_PRODUCER="{hipcc_producer()}"'] + list(defs) + SOURCES + ["-o", target]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -1331,9 +1331,20 @@ extern "C" int pt_spec_wait(pt_ctx *c)
     if (st < 0) set_err("per-scene build: %s", spec_log(c->spec));
     return st;
 }
+// Who compiled the module this context launches: one line of JSON (pt_spec.cpp spec_info) -- "built_by": "helper" (the compile
+// helper beside the library, this toolchain's hiprtc) or "in-process" (whatever libhiprtc the host process resolves), the path
+// of that libhiprtc, the producer string of the code object and whether it is the compiler that built this library.  Returns
+// the text length; buf receives it when cap > length.
+extern "C" int pt_spec_info(pt_ctx *c, char *buf, size_t cap)
+{
+    if (!c) { set_err("pt_spec_info: null ctx"); return -1; }
+    const std::string t = c->spec ? spec_info(c->spec) : std::string("{\"status\": -1, \"built_by\": null, \"note\": \"no per-scene build for this context\"}");
+    if (buf && cap > t.size()) memcpy(buf, t.c_str(), t.size() + 1);
+    return (int)t.size();
+}
 // Host-only check of the per-scene build (no device): compiles the module for gfx950 and returns the size of its code
 // object, < 0 on failure (pt_last_error has the compiler's log).
-extern "C" long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_samples)
+static long spec_check(const pt_scene_desc *scene, int32_t light_samples, std::string *info)
 {
     std::string table, log;
     if (spec_header_text(scene, table) <= 0) return -2;
@@ -1344,9 +1355,19 @@ extern "C" long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_sa
         const pt_material &m = scene->materials[i];
         textured |= m.texture >= 0 && (m.type == PT_MAT_LAMBERTIAN || m.type == PT_MAT_DIFFUSE_LIGHT || m.type == PT_MAT_ISOTROPIC);
     }
-    const long n = spec_build_check(table, hp.geom_all != 0, textured, (light_samples % 2 == 0) ? 2 : 1, log);
+    const long n = spec_build_check(table, hp.geom_all != 0, textured, (light_samples % 2 == 0) ? 2 : 1, log, info);
     if (n < 0) set_err("per-scene build: %s", log.c_str());
     return n;
+}
+extern "C" long pt_spec_build_check(const pt_scene_desc *scene, int32_t light_samples) { return spec_check(scene, light_samples, nullptr); }
+// The same check, answering with pt_spec_info's line for the module it built (host only): which compiler a context of this
+// scene would get in this process.  Returns the text length (buf receives it when cap > length), < 0 when the build failed.
+extern "C" int pt_spec_build_info(const pt_scene_desc *scene, int32_t light_samples, char *buf, size_t cap)
+{
+    std::string info;
+    if (spec_check(scene, light_samples, &info) < 0) return -1;
+    if (buf && cap > info.size()) memcpy(buf, info.c_str(), info.size() + 1);
+    return (int)info.size();
 }
 extern "C" int pt_set_profiling(pt_ctx *c, int enabled)
 {

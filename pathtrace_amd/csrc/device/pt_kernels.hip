@@ -1499,13 +1499,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
     // (chunk, seg) of the next chunk advance by the grid stride without a division per chunk
     ChunkWalk nx;
     nx.init(b.n_seg, b.perm);
-    const int end_chunks = B0 ? total_chunks : chunk_limit(st.qmax, 0, bounce - 1, b.n_seg, total_chunks);   // see chunk_limit
+    // see chunk_limit.  Chunk 0 of every segment is visited whatever the bound says (chunk-major: its indices are [0, n_seg)):
+    // that is where this bounce's output counters are zeroed, and a batch whose paths have all died (bound 0) must still
+    // zero them -- else the consumers of a later bounce that trusts the counts again (bounce >= PT_QMAX_BOUNCES, k_tally)
+    // would meet the last live bounce's values and walk its stale records a second time.
+    const int end_bound = B0 ? total_chunks : chunk_limit(st.qmax, 0, bounce - 1, b.n_seg, total_chunks);
+    const int end_chunks = max(end_bound, min(b.n_seg, total_chunks));
     int n_ahead = ((int)blockIdx.x < end_chunks) ? seg_live<B0>(q, b, nx.seg) : 0;
     for (int c = blockIdx.x; c < end_chunks; c += gridDim.x) {
         // chunk-major order: the live chunks of every segment are its first few, so they sit together at the front of
         // the index space and spread evenly over the workgroups (segment-major order would alias with the stride)
         const int chunk = nx.chunk, seg = nx.seg;
-        const int n = n_ahead;
+        const int n = (c < end_bound) ? n_ahead : 0;   // beyond the bound every segment is empty (its count word may be stale)
         nx.advance();
         if (c + (int)gridDim.x < end_chunks) n_ahead = seg_live<B0>(q, b, nx.seg);
         if (chunk == 0 && threadIdx.x == 0 && (seg & 1) == 0) {
@@ -2358,16 +2363,23 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int q
 {
     const DQueue q = st.q[qi];
     const int cps = b.seg_cap / PT_BLOCK, total_chunks = b.n_seg * cps;
+    // the kernels' own bounds (chunk_limit): no segment of the path queue holds more than live_p entries, none of the shadow
+    // queue more than live_s -- a count word beyond them is not trusted (k_extend zeroes the words of every bounce, also of a
+    // batch whose paths have all died; the bound keeps this walk short as well)
+    const int live_p = (PT_FUSE_GENERATE && bounce == 0) ? cps : chunk_limit(st.qmax, 0, bounce - 1, 1, cps);
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {           // the paths this bounce extended
         const int seg = c / cps, i = (c - seg * cps) * PT_BLOCK + (int)threadIdx.x;
+        if (c - seg * cps >= live_p) continue;
         if (i >= ((PT_FUSE_GENERATE && bounce == 0) ? seg_live<true>(q, b, seg) : seg_live<false>(q, b, seg))) continue;
         const long long pos = (long long)seg * b.seg_cap + i;
         const int slot = (PT_FUSE_GENERATE && bounce == 0) ? (int)pos : __float_as_int(q.r0[pos].w);
         atomicAdd(cost + tile_of_slot(b, slot), 1ull);
     }
     const int cps_o = b.seg_cap_out / PT_BLOCK, total_o = b.n_seg_out * cps_o;
+    const int live_s = chunk_limit(st.qmax, 1, bounce, 1, cps_o);
     for (int c = blockIdx.x; c < total_o; c += gridDim.x) {                // the shadow records this bounce wrote
         const int seg = c / cps_o, i = (c - seg * cps_o) * PT_BLOCK + (int)threadIdx.x;
+        if (c - seg * cps_o >= live_s) continue;
         if (i >= st.sq.count[seg]) continue;
         const int slot = __float_as_int(st.sq.p0[(long long)seg * b.seg_cap_out + i].w) & 0x7fffffff;
         atomicAdd(cost + tile_of_slot(b, slot), (unsigned long long)light_samples);

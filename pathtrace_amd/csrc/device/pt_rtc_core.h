@@ -51,6 +51,7 @@ struct Request {
 struct Result {
     int status = -1;                    // 0: code and lowered names are valid
     std::string log;
+    std::string rtc_path;               // the libhiprtc file that compiled (dladdr of hiprtcCompileProgram), "" when unknown
     std::vector<std::string> lowered;   // one per name expression
     std::vector<char> code;
 };
@@ -61,6 +62,10 @@ inline void run(Rtc &rtc, const Request &q, Result &r)
     std::vector<const char *> htext, hname, opts;
     for (const auto &h : q.headers) { hname.push_back(h.first.c_str()); htext.push_back(h.second.c_str()); }
     for (const auto &o : q.opts) opts.push_back(o.c_str());
+    {   // which file the compiler is: the path dlopen resolved (a wheel's bundled libhiprtc answers to the same soname)
+        Dl_info info;
+        if (rtc.CompileProgram && dladdr((const void *)rtc.CompileProgram, &info) && info.dli_fname) r.rtc_path = info.dli_fname;
+    }
     void *prog = nullptr;
     if (rtc.CreateProgram(&prog, q.top.c_str(), q.top_name.c_str(), (int)htext.size(), htext.data(), hname.data()) != 0) { r.log = "hiprtcCreateProgram failed"; return; }
     bool ok = true;
@@ -127,7 +132,7 @@ inline bool write_result(const char *path, const Result &r)
 {
     FILE *f = fopen(path, "wb");
     if (!f) return false;
-    put(f, std::string("PTRTCR1")); put(f, std::to_string(r.status)); put(f, r.log);
+    put(f, std::string("PTRTCR2")); put(f, std::to_string(r.status)); put(f, r.log); put(f, r.rtc_path);
     put(f, std::to_string(r.lowered.size()));
     for (const auto &l : r.lowered) put(f, l);
     put(f, r.code.data(), r.code.size());
@@ -138,9 +143,9 @@ inline bool read_result(const char *path, Result &r)
     FILE *f = fopen(path, "rb");
     if (!f) return false;
     std::string magic, n, code;
-    bool ok = get(f, magic) && magic == "PTRTCR1" && get(f, n);
+    bool ok = get(f, magic) && magic == "PTRTCR2" && get(f, n);
     if (ok) r.status = atoi(n.c_str());
-    ok = ok && get(f, r.log) && get(f, n);
+    ok = ok && get(f, r.log) && get(f, r.rtc_path) && get(f, n);
     for (int i = 0, c = ok ? atoi(n.c_str()) : 0; ok && i < c; i++) { std::string l; ok = get(f, l); r.lowered.push_back(l); }
     ok = ok && get(f, code);
     if (ok) r.code.assign(code.begin(), code.end());

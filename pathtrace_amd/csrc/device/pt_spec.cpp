@@ -15,7 +15,7 @@
 #include <hip/hip_ext.h>
 
 #ifndef _GNU_SOURCE
-#define _GNU_SOURCE   // dlmopen
+#define _GNU_SOURCE   // dladdr
 #endif
 #include <dlfcn.h>
 
@@ -40,9 +40,11 @@
 
 #include "pt_rtc_core.h"
 #include "pt_spec.h"
-extern char **environ;
 #ifndef PT_ROCM_LIB_DIR
 #define PT_ROCM_LIB_DIR "/opt/rocm/lib"
+#endif
+#ifndef PT_HIPCC_PRODUCER
+#define PT_HIPCC_PRODUCER ""   // "clang version X.Y.Z" of the hipcc that built this library (pathtrace_amd/build.py), "" = unknown
 #endif
 
 namespace ptd {
@@ -63,15 +65,39 @@ static const char *const kBuildFlags[] = {
 };
 
 namespace {
-ptrtc::Rtc g_rtc;          // the in-process compiler (fallback)
-std::mutex g_rtc_mutex;    // one compile at a time (comgr is heavy, and the cache below is filled under it)
-
+// Process-wide state of the build.  Heap-allocated and never destroyed on purpose: an asynchronous build may still run when
+// the process exits or the library is unloaded (a Renderer never closed, an exception path, interpreter shutdown), and a
+// static destructor running under the worker's feet -- the cache map, the mutex it holds -- crashed at exit.
 struct CodeObject {
     std::vector<char> code;
     std::string name_extend[2], name_connect, name_trace[3];   // k_extend: [1] = the bounce-0 instantiation (forms its camera rays)
     int connect_nr = 2;
+    // provenance (pt_spec_info): who compiled it
+    bool by_helper = false;
+    std::string rtc_path, producer, note;   // note: why the helper did not compile it, when it did not
 };
-std::map<std::string, std::shared_ptr<CodeObject>> g_cache;   // key: table text + flags
+struct Globals {
+    ptrtc::Rtc rtc;          // the in-process compiler (fallback)
+    std::mutex rtc_mutex;    // one compile at a time (comgr is heavy, and the cache below is filled under it)
+    std::map<std::string, std::shared_ptr<CodeObject>> cache;   // key: table text + flags
+};
+Globals &G() { static Globals *g = new Globals(); return *g; }
+
+// Every environment knob of the build, read ONCE on the thread that asks for the build (spec_start / spec_build_check): the
+// worker thread must not call getenv while the host thread may call setenv (Python's os.environ, a test's monkeypatch).
+struct SpecEnv {
+    std::string waves, generic, flags, pf, brk, dump, cc, rtc_shared, rtc_lib, tmpdir, path;
+    static std::string get(const char *n) { const char *v = getenv(n); return v ? v : ""; }
+    static SpecEnv snapshot()
+    {
+        SpecEnv e;
+        e.waves = get("PATHTRACE_HIP_SPEC_WAVES"); e.generic = get("PATHTRACE_HIP_SPEC_GENERIC"); e.flags = get("PATHTRACE_HIP_SPEC_FLAGS");
+        e.pf = get("PATHTRACE_HIP_SPEC_PF"); e.brk = get("PATHTRACE_HIP_SPEC_BREAK"); e.dump = get("PATHTRACE_HIP_SPEC_DUMP");
+        e.cc = get("PATHTRACE_HIP_SPEC_CC"); e.rtc_shared = get("PATHTRACE_HIP_RTC_SHARED"); e.rtc_lib = get("PATHTRACE_HIP_RTC_LIB");
+        e.tmpdir = get("TMPDIR"); e.path = get("PATH");
+        return e;
+    }
+};
 
 // The directory this library was loaded from: its compile helper (pt_spec_cc) sits beside it.
 std::string library_dir()
@@ -83,35 +109,59 @@ std::string library_dir()
     return k == std::string::npos ? "." : p.substr(0, k);
 }
 
+// Where this toolchain's libhiprtc / libamd_comgr live, resolved when the build runs: the directory the library was built
+// against as hipcc was named (normally /opt/rocm/lib: the symlink, not the versioned directory behind it) if it is there,
+// else /opt/rocm/lib.
+std::string rocm_lib_dir()
+{
+    for (const char *d : {PT_ROCM_LIB_DIR, "/opt/rocm/lib"}) {
+        const std::string f = std::string(d) + "/libhiprtc.so";
+        if (access(f.c_str(), R_OK) == 0) return d;
+    }
+    return PT_ROCM_LIB_DIR;
+}
+
 // The compilation in a process of its own.  Why: the compiler must be the toolchain this library was built with.  A host
 // process may already hold ANOTHER ROCm's libhiprtc / libamd_comgr under the same sonames -- PyTorch wheels bundle theirs
 // (roc-7.0 / LLVM 20 in this image, against /opt/rocm's roc-7.2 / LLVM 22) -- and dlopen("libhiprtc.so"), and hiprtc's own
 // dlopen of comgr, then return THOSE: the module was being built by the older compiler, whose code for these kernels is
 // different (generic k_connect: 24 spilled VGPRs and 76 B of scratch against none; 25.6 against 13.0 ms per 64 spp).  A child
-// process holds nothing but what it loads itself.  (A second link-map namespace, dlmopen, does the same in-process and was
-// tried first: it crashed after some twenty compilations beside a live HIP runtime.)  The helper never touches the GPU.
+// process holds nothing but what it loads itself -- and is given an environment of its own making: the host's
+// LD_LIBRARY_PATH (hiprtc opens comgr by soname, and LD_LIBRARY_PATH beats RUNPATH: a torch/lib in front would bring the
+// other compiler back), LD_PRELOAD and the profilers' ROCP_* / HSA_TOOLS_LIB variables (under rocprofv3 the tool library
+// would load in a process that must never touch the GPU) do not reach it.  The helper never touches the GPU.
 // Returns false when the helper could not be run at all (missing file, spawn failure): the caller then compiles in-process.
-bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &why)
+bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &why, const SpecEnv &env, std::atomic<int> *child_pid,
+                      const std::atomic<bool> *cancel)
 {
-    const char *forced = getenv("PATHTRACE_HIP_SPEC_CC");
-    const std::string exe = forced ? std::string(forced) : library_dir() + "/pt_spec_cc";
+    const std::string exe = !env.cc.empty() ? env.cc : library_dir() + "/pt_spec_cc";
     if (access(exe.c_str(), X_OK) != 0) { why = exe + " is not there"; return false; }
-    const char *tmp = getenv("TMPDIR");
+    const std::string tmp = env.tmpdir.empty() ? "/tmp" : env.tmpdir;
     char req[512], res[512];
-    snprintf(req, sizeof req, "%s/pt_spec_req_XXXXXX", tmp && *tmp ? tmp : "/tmp");
-    snprintf(res, sizeof res, "%s/pt_spec_res_XXXXXX", tmp && *tmp ? tmp : "/tmp");
+    snprintf(req, sizeof req, "%s/pt_spec_req_XXXXXX", tmp.c_str());
+    snprintf(res, sizeof res, "%s/pt_spec_res_XXXXXX", tmp.c_str());
     const int fq = mkstemp(req), fr = mkstemp(res);
     if (fq >= 0) close(fq);
     if (fr >= 0) close(fr);
     bool ran = false;
     if (fq >= 0 && fr >= 0 && ptrtc::write_request(req, q)) {
         char *const argv[] = {(char *)exe.c_str(), req, res, nullptr};
+        const std::string libdir = rocm_lib_dir();
+        std::vector<std::string> ev = {"PATH=" + (env.path.empty() ? std::string("/usr/bin:/bin") : env.path), "TMPDIR=" + tmp,
+                                       "LD_LIBRARY_PATH=" + libdir, "PT_SPEC_ROCM_LIB_DIR=" + libdir};
+        if (!env.rtc_lib.empty()) ev.push_back("PATHTRACE_HIP_RTC_LIB=" + env.rtc_lib);
+        std::vector<char *> envp;
+        for (auto &e : ev) envp.push_back(&e[0]);
+        envp.push_back(nullptr);
         pid_t pid = 0;
-        if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, environ) == 0) {
-            // wait for it, at most two minutes (a compilation takes 1.5 - 3 s): a helper that hangs is killed, not waited for
+        if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, envp.data()) == 0) {
+            if (child_pid) child_pid->store((int)pid);
+            // wait for it, at most two minutes (a compilation takes 1.5 - 3 s): a helper that hangs is killed, not waited for;
+            // a context destroyed meanwhile (cancel) kills it too
             int status = 0, w = 0;
-            bool gone = false;
+            bool gone = false, cancelled = false;
             for (int tick = 0; tick < 6000 && !gone; tick++) {
+                if (cancel && cancel->load()) { cancelled = true; break; }
                 w = waitpid(pid, &status, WNOHANG);
                 if (w == pid) gone = true;
                 else if (w < 0 && errno != EINTR) {   // a host that ignores SIGCHLD reaps children itself (ECHILD): watch the pid
@@ -119,7 +169,13 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
                     else usleep(20000);
                 } else usleep(20000);
             }
-            if (!gone) { kill(pid, SIGKILL); while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {} why = "pt_spec_cc did not finish in two minutes"; }
+            if (child_pid) child_pid->store(0);
+            if (!gone) {
+                kill(pid, SIGKILL);
+                while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+                why = cancelled ? "the context was destroyed while its module was being built" : "pt_spec_cc did not finish in two minutes";
+                if (cancelled) ran = true, r.status = -1, r.log = why;   // not a reason to compile in-process
+            }
             else if (WIFEXITED(status) && WEXITSTATUS(status) == 0 && ptrtc::read_result(res, r)) ran = true;
             else why = "pt_spec_cc ended abnormally";
         } else why = "posix_spawn(pt_spec_cc) failed";
@@ -128,23 +184,40 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
     if (fr >= 0) unlink(res);
     return ran;
 }
+
+// the producer string of a code object: the "... clang version X.Y.Z (...)" text of its .comment section
+std::string producer_of(const std::vector<char> &code)
+{
+    static const char key[] = "clang version ";
+    const size_t kl = sizeof key - 1;
+    for (size_t i = 0; i + kl < code.size(); i++) {
+        if (memcmp(&code[i], key, kl) != 0) continue;
+        size_t a = i, b = i;
+        while (a > 0 && code[a - 1] >= 32 && code[a - 1] < 127) a--;
+        while (b < code.size() && code[b] >= 32 && code[b] < 127) b++;
+        return std::string(&code[a], b - a);
+    }
+    return "";
+}
 }  // namespace
 
 // One build.  `table` is the PT_SPEC_HEADER text.  Returns the code object or nullptr with `log` set.
-static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_all, bool textured, int connect_nr, std::string &log)
+static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_all, bool textured, int connect_nr, std::string &log, const SpecEnv &env,
+                                           std::atomic<int> *child_pid = nullptr, const std::atomic<bool> *cancel = nullptr)
 {
     char flags[256];
-    snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, getenv("PATHTRACE_HIP_SPEC_WAVES") ? getenv("PATHTRACE_HIP_SPEC_WAVES") : "5",
-             getenv("PATHTRACE_HIP_SPEC_GENERIC") ? 1 : 0);
-    const std::string key = table + flags + (getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "") + (getenv("PATHTRACE_HIP_SPEC_PF") ? getenv("PATHTRACE_HIP_SPEC_PF") : "");
-    std::lock_guard<std::mutex> lock(g_rtc_mutex);
-    if (getenv("PATHTRACE_HIP_SPEC_BREAK")) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
-    auto hit = g_cache.find(key);
-    if (hit != g_cache.end()) return hit->second;
+    snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, env.waves.empty() ? "5" : env.waves.c_str(),
+             env.generic.empty() ? 0 : 1);
+    const std::string key = table + flags + env.flags + env.pf + "|" + env.rtc_shared + "|" + env.cc + "|" + env.rtc_lib;
+    Globals &g = G();
+    std::lock_guard<std::mutex> lock(g.rtc_mutex);
+    if (!env.brk.empty()) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
+    auto hit = g.cache.find(key);
+    if (hit != g.cache.end()) return hit->second;
     ptrtc::Request q;
     // PATHTRACE_HIP_SPEC_GENERIC (measurement): the module holds the GENERIC kernels -- the library's own code through the module path
-    q.top = getenv("PATHTRACE_HIP_SPEC_GENERIC") ? "#define PT_SPEC_BUILD 1\n#include \"pt_kernels.hip\"\n"
-                                                 : "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
+    q.top = !env.generic.empty() ? "#define PT_SPEC_BUILD 1\n#include \"pt_kernels.hip\"\n"
+                                 : "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
     q.top_name = "pt_spec_top.hip";
     q.headers = {{"pt_kernels.hip", kSrcKernels}, {"pt_device.h", kSrcDevice}, {"pt_fdiv.h", kSrcFdiv}, {"pt_spec_table.h", table}};
     const char *ga = geom_all ? "true" : "false", *tex = textured ? "true" : "false";
@@ -157,11 +230,11 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17) and without the early radiance request, which at this
     // register budget is spilled the moment it arrives
     const char *waves = "-DPT_CONNECT_WAVES=5";
-    if (const char *w = getenv("PATHTRACE_HIP_SPEC_WAVES")) { if (!strcmp(w, "4")) waves = "-DPT_CONNECT_WAVES=4"; else if (!strcmp(w, "6")) waves = "-DPT_CONNECT_WAVES=6"; }
+    if (env.waves == "4") waves = "-DPT_CONNECT_WAVES=4"; else if (env.waves == "6") waves = "-DPT_CONNECT_WAVES=6";
     q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
-    if (!getenv("PATHTRACE_HIP_SPEC_GENERIC")) { q.opts.push_back(waves); const char *pf = getenv("PATHTRACE_HIP_SPEC_PF"); q.opts.push_back(pf && pf[0] == '1' ? "-DPT_CONNECT_PREFETCH=1" : (pf && pf[0] == '2' ? "-DPT_CONNECT_PREFETCH=2" : "-DPT_CONNECT_PREFETCH=0")); }
+    if (env.generic.empty()) { q.opts.push_back(waves); q.opts.push_back(env.pf == "1" ? "-DPT_CONNECT_PREFETCH=1" : (env.pf == "2" ? "-DPT_CONNECT_PREFETCH=2" : "-DPT_CONNECT_PREFETCH=0")); }
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
-    std::string extra = getenv("PATHTRACE_HIP_SPEC_FLAGS") ? getenv("PATHTRACE_HIP_SPEC_FLAGS") : "";   // measurement: more compiler options, space separated
+    const std::string &extra = env.flags;   // measurement: more compiler options, space separated
     for (size_t i = 0; i < extra.size();) {
         const size_t j = extra.find(' ', i);
         if (j != i) q.opts.push_back(extra.substr(i, j == std::string::npos ? j : j - i));
@@ -170,10 +243,13 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     }
     ptrtc::Result r;
     std::string why;
+    bool by_helper = true;
     // PATHTRACE_HIP_RTC_SHARED=1 (the A/B): compile in-process with whatever libhiprtc the process resolves
-    if (getenv("PATHTRACE_HIP_RTC_SHARED") || !compile_in_child(q, r, why)) {
-        if (!g_rtc.load({"libhiprtc.so", "libhiprtc.so.7", PT_ROCM_LIB_DIR "/libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"})) { log = "no compiler: " + (why.empty() ? std::string() : why + "; ") + "libhiprtc.so could not be loaded"; return nullptr; }
-        ptrtc::run(g_rtc, q, r);
+    if (!env.rtc_shared.empty() || !compile_in_child(q, r, why, env, child_pid, cancel)) {
+        by_helper = false;
+        const std::string dir = rocm_lib_dir();
+        if (!g.rtc.load({dir + "/libhiprtc.so", "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})) { log = "no compiler: " + (why.empty() ? std::string() : why + "; ") + "libhiprtc.so could not be loaded"; return nullptr; }
+        ptrtc::run(g.rtc, q, r);
     }
     if (r.status != 0 || r.lowered.size() != 6 || r.code.empty()) { log = r.log.empty() ? "the per-scene build produced no code object" : r.log; return nullptr; }
     auto obj = std::make_shared<CodeObject>();
@@ -181,10 +257,14 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     obj->name_extend[0] = r.lowered[0]; obj->name_extend[1] = r.lowered[1]; obj->name_connect = r.lowered[2];
     for (int i = 0; i < 3; i++) obj->name_trace[i] = r.lowered[3 + i];
     obj->code = std::move(r.code);
-    if (const char *dump = getenv("PATHTRACE_HIP_SPEC_DUMP")) {   // the code object, for llvm-objdump / tools/isa_stats.py
-        if (FILE *fh = fopen(dump, "wb")) { fwrite(obj->code.data(), 1, obj->code.size(), fh); fclose(fh); }
+    obj->by_helper = by_helper;
+    obj->rtc_path = r.rtc_path;
+    obj->producer = producer_of(obj->code);
+    if (!by_helper && !why.empty()) obj->note = "compiled in-process: " + why;
+    if (!env.dump.empty()) {   // the code object, for llvm-objdump / tools/isa_stats.py
+        if (FILE *fh = fopen(env.dump.c_str(), "wb")) { fwrite(obj->code.data(), 1, obj->code.size(), fh); fclose(fh); }
     }
-    g_cache[key] = obj;
+    g.cache[key] = obj;
     return obj;
 }
 
@@ -202,15 +282,19 @@ struct SpecJob {
     hipModule_t module = nullptr;
     hipFunction_t f_extend[2] = {nullptr, nullptr}, f_connect = nullptr, f_trace[3] = {nullptr, nullptr, nullptr};
     std::atomic<int> state{0};   // 0 building, 1 module loaded, -1 failed
+    SpecEnv env;                 // the build's environment knobs as the creating thread saw them
+    std::atomic<int> child_pid{0};
+    std::atomic<bool> cancel{false};   // spec_destroy: the context is going away, a compile helper still running is killed
 };
 
 SpecJob *spec_start(const std::string &table, bool geom_all, bool textured, int connect_nr, int device, bool synchronous)
 {
     SpecJob *j = new SpecJob();
     j->table = table; j->geom_all = geom_all; j->textured = textured; j->connect_nr = connect_nr; j->device = device;
+    j->env = SpecEnv::snapshot();
     auto work = [j]() {
         std::string log;
-        auto obj = compile(j->table, j->geom_all, j->textured, j->connect_nr, log);
+        auto obj = compile(j->table, j->geom_all, j->textured, j->connect_nr, log, j->env, &j->child_pid, &j->cancel);
         std::lock_guard<std::mutex> lock(j->m);
         j->obj = obj; j->log = log; j->done = true;
         j->cv.notify_all();
@@ -258,10 +342,39 @@ int spec_wait(SpecJob *j)
 
 const char *spec_log(SpecJob *j) { return j ? j->log.c_str() : ""; }
 
+// Who compiled a module (pt_spec_info): one line of JSON.  own_compiler: the code object's producer string is the hipcc's
+// that built this library (PT_HIPCC_PRODUCER, recorded by build.py) -- false means a FOREIGN compiler built the kernels the
+// context launches (measured: PyTorch's bundled clang 20 makes k_connect 2x slower), null = unknown.
+static std::string json_escape(const std::string &t)
+{
+    std::string o;
+    for (char ch : t) { if (ch == '"' || ch == '\\') o += '\\'; if ((unsigned char)ch >= 32) o += ch; }
+    return o;
+}
+static std::string info_of(const CodeObject *obj, int status, const std::string &note)
+{
+    if (!obj) return "{\"status\": " + std::to_string(status) + ", \"built_by\": null" + (note.empty() ? "" : ", \"note\": \"" + json_escape(note.substr(0, 300)) + "\"") + "}";
+    const std::string own = PT_HIPCC_PRODUCER;
+    std::string o = "{\"status\": " + std::to_string(status) + ", \"built_by\": \"" + (obj->by_helper ? "helper" : "in-process") + "\", \"rtc_lib\": \"" + json_escape(obj->rtc_path) +
+                    "\", \"producer\": \"" + json_escape(obj->producer) + "\", \"library_producer\": \"" + json_escape(own) + "\", \"own_compiler\": ";
+    o += own.empty() || obj->producer.empty() ? "null" : (obj->producer.find(own) != std::string::npos ? "true" : "false");
+    const std::string all = obj->note.empty() ? note : (note.empty() ? obj->note : obj->note + "; " + note);
+    if (!all.empty()) o += ", \"note\": \"" + json_escape(all.substr(0, 300)) + "\"";
+    return o + "}";
+}
+std::string spec_info(SpecJob *j)
+{
+    if (!j) return info_of(nullptr, -1, "no per-scene build");
+    std::lock_guard<std::mutex> lock(j->m);
+    if (!j->done) return info_of(nullptr, 0, "");
+    return info_of(j->obj.get(), j->obj ? j->state.load() : -1, j->log);
+}
+
 void spec_destroy(SpecJob *j)
 {
     if (!j) return;
-    if (j->worker.joinable()) j->worker.join();   // a build in flight is waited for: its thread must not outlive the library
+    j->cancel.store(true);                        // a compile helper still running is killed by its waiter: a short-lived context
+    if (j->worker.joinable()) j->worker.join();   // does not sit out the compilation; the thread itself is joined (it must not outlive the job)
     if (j->module) (void)hipModuleUnload(j->module);
     delete j;
 }
@@ -312,9 +425,10 @@ int spec_launch_trace(SpecJob *j, int nr, int grid, size_t lds, hipStream_t s, c
 int spec_connect_nr(SpecJob *j) { return j ? j->connect_nr : 0; }
 
 // host-only check (no device): build the module of a table and report the size of its code object, < 0 with the log on failure
-long spec_build_check(const std::string &table, bool geom_all, bool textured, int connect_nr, std::string &log)
+long spec_build_check(const std::string &table, bool geom_all, bool textured, int connect_nr, std::string &log, std::string *info)
 {
-    auto obj = compile(table, geom_all, textured, connect_nr, log);
+    auto obj = compile(table, geom_all, textured, connect_nr, log, SpecEnv::snapshot());
+    if (info) *info = info_of(obj.get(), obj ? 1 : -1, log);
     return obj ? (long)obj->code.size() : -1;
 }
 

@@ -20,7 +20,10 @@ int main(int argc, char **argv)
     ptrtc::Rtc rtc;
     std::vector<std::string> candidates;
     if (const char *forced = getenv("PATHTRACE_HIP_RTC_LIB")) candidates.push_back(forced);
-    candidates.push_back(PT_ROCM_LIB_DIR "/libhiprtc.so.7");
+    // the directory the library resolved when it started this process (pt_spec.cpp rocm_lib_dir), then the one this helper was
+    // built against, then the usual place; by soname last (the environment pt_spec.cpp gives this process has LD_LIBRARY_PATH =
+    // that directory, so hiprtc's own dlopen of libamd_comgr finds the same toolchain's)
+    if (const char *dir = getenv("PT_SPEC_ROCM_LIB_DIR")) candidates.push_back(std::string(dir) + "/libhiprtc.so");
     candidates.push_back(PT_ROCM_LIB_DIR "/libhiprtc.so");
     candidates.push_back("/opt/rocm/lib/libhiprtc.so");
     candidates.push_back("libhiprtc.so");

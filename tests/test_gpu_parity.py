@@ -231,6 +231,47 @@ def test_cost_balanced_tile_ownership(oracle):
     r.close()
 
 
+@pytest.mark.parametrize("spec", ["off", "sync"])
+@pytest.mark.parametrize("scene,max_bounces", [("cornell_box", 80), ("three_orbs", 100), ("cornell_box_with_volume", 70)])
+def test_more_bounces_than_live_count_words(oracle, scene, max_bounces, spec, monkeypatch):
+    # The live-count bound of the queues (pt_kernels.hip chunk_limit) has words for 64 bounces; later ones trust the
+    # segment counters again.  With russian roulette every batch is dead long before: the counters of every bounce must
+    # then read zero (k_extend zeroes them whatever the bound says), else bounce 64 walks the stale records of the bounce
+    # where the paths died a second time.  The reference accepts any max_bounces (config.h:116).
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC", spec)
+    w, h, spp = 64, 36, 3
+    kw = dict(max_bounces=max_bounces)
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp, **kw), seed=2)
+    gpu, gc = gpu_render(scene, w, h, spp, seed=2, **kw)
+    assert_bit_identical(gpu, ref, f"{scene} max_bounces={max_bounces}")
+    assert_counters(gc, oc, f"{scene} max_bounces={max_bounces}")
+    # small slot budgets: many batches, each dead at its own bounce
+    gpu2, gc2 = gpu_render(scene, w, h, spp, seed=2, max_paths=700, **kw)
+    assert np.array_equal(bits(gpu), bits(gpu2)) and gc == gc2
+
+
+@pytest.mark.parametrize("scene,max_bounces", [("three_orbs", 50), ("light_test", 12), ("cornell_box", 50)])
+def test_tile_costs_equal_traced_rays_when_batches_die_early(scene, max_bounces):
+    # pt_measure_tile_costs' contract: a tile's cost = the rays the device traces for it + one per pixel.  Open scenes and
+    # small batches die many bounces before max_bounces: the tally of the remaining bounces must add nothing.
+    from pathtrace_amd.distributed import measure_tile_costs
+
+    w, h, tile = 160, 90, 32
+    sc = pt.Scene(scene_path(scene), w, h)
+    tiles = pt.spiral_tiles(w, h, tile, tile)
+    for max_paths in (0, 3000):
+        r = pt.Renderer(sc, max_bounces=max_bounces, max_paths_in_flight=max_paths)
+        costs = measure_tile_costs(r, tiles)
+        for k in (0, len(tiles) // 3, len(tiles) - 1):
+            r.clear()
+            r.render_tiles_async([tiles[k]], 0, 1)
+            assert costs[k] == r.counters()["rays_traced"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1]), (scene, max_paths, k)
+        r.clear()
+        r.render_tiles_async(tiles, 0, 1)
+        assert sum(costs) == r.counters()["rays_traced"] + w * h
+        r.close()
+
+
 def test_progressive_snapshot_of_the_live_framebuffer(tmp_path):
     # SURVEY 8f-3 (renderer.h:605-620): the preview reads the framebuffer while the render is still running.  A snapshot
     # must not wait for the queued work, its sample count is monotone, every pixel is a prefix sum of that pixel's

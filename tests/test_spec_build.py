@@ -73,3 +73,29 @@ def test_without_a_working_helper_the_build_runs_in_process(helper, monkeypatch)
     monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_NO_HELPER_%d=1" % len(helper))   # a key nothing has cached
     sc = pt.Scene(scene_path("three_orbs"), 40, 30)
     assert pt.spec_build_check(sc, 6) > 20000
+
+
+def test_provenance_names_the_compiler_and_survives_a_hostile_environment(monkeypatch):
+    # pt_spec_info / pt_spec_build_info: which process compiled, which libhiprtc file, the code object's producer string and
+    # whether it is the compiler the library was built with.  The helper is started with an environment of the library's own
+    # making: an LD_LIBRARY_PATH that puts PyTorch's bundled ROCm first (hiprtc opens libamd_comgr by soname), an LD_PRELOAD
+    # or a profiler's tool library in the host's environment must not reach it.
+    import os
+    import torch
+
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    monkeypatch.setenv("LD_LIBRARY_PATH", torch_lib + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    monkeypatch.setenv("LD_PRELOAD", "/nonexistent/libtool.so")
+    monkeypatch.setenv("HSA_TOOLS_LIB", "/nonexistent/librocprofiler-sdk-tool.so")
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_PROVENANCE=1")   # a key nothing has cached
+    sc = pt.Scene(scene_path("cornell_box"), 32, 32)
+    info = pt.spec_build_info(sc, 4)
+    assert info["built_by"] == "helper" and info["own_compiler"] is True, info
+    assert "/opt/rocm" in info["rtc_lib"] and "torch" not in info["rtc_lib"], info
+    assert info["producer"].startswith("AMD clang version") and info["library_producer"] in info["producer"]
+    # without the helper the in-process compiler is whatever the process resolves: the record says so
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_CC", "/nonexistent/pt_spec_cc")
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_PROVENANCE=2")
+    info = pt.spec_build_info(sc, 4)
+    assert info["built_by"] == "in-process" and "is not there" in info.get("note", ""), info
+    assert info["own_compiler"] in (True, False) and info["producer"]
