@@ -24,7 +24,9 @@ Launch plan (`launch_plan`): a rank's K steps are cut into wavefront batches of 
 N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
 partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over per-tile ray counts measured
 in one pass (pt_measure_tile_costs; PT_BENCH_ROUND_ROBIN=1 = tile k -> rank k mod N).  Every rank renders ITS tiles
-for all K steps with no communication and ONE RCCL sum-reduce of the framebuffer to rank 0 ends the timed region.
+for all K steps with no communication and ONE collective ends the timed region: a gather of every rank's OWN tiles
+(1/N of the frame each, pathtrace_amd.distributed.OwnedTileExchange; RCCL over xGMI) into rank 0's framebuffer --
+(N-1)/N of one frame over the links instead of the N-1 whole frames a sum-reduce moves (PT_BENCH_EXCHANGE=reduce: that form).
 PT_BENCH_SCALING=weak keeps per-GPU work fixed instead (every step renders 16*N spp).
 
 The timed region holds only GPU work on device-resident data (scene tables + streams live in HBM; there are no host
@@ -56,6 +58,7 @@ if os.environ.get("PT_BENCH_SIZE"):   # e.g. 3840x2160 for BASELINE config 5's f
 SCENE = os.path.join(ROOT, "scenes", "cornell_box.json")
 SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
+LIGHT_SAMPLES = 4              # BASELINE configs: light_samples 4 (pt.Renderer's default)
 N_LANES = 3                    # stream lanes of a context (pt_context.cpp; PATHTRACE_HIP_LANES)
 MAX_BATCH_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", str(1920 * 1080 * 32)))   # 66 M path slots x 288 B x 3 lanes = 57 GB
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -63,6 +66,52 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_fma_f32 2 cycles per wave64 = 157.3 TFLOP/s); other vector instruction classes issue at 4 or more cycles
 VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2
 PIPELINE_BYTES_PER_RAY_16x9 = 153.0         # whole pipeline, cornell_box 16:9
+
+
+# What a vector instruction costs to issue on one SIMD (tools/microbench/valu_rates.hip): classes of tools/isa_stats.py
+ISSUE_CYCLES = {"fp2": 2.0, "fp2s": 4.0, "v4": 4.0, "pk": 4.0, "trans": 8.0}
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def reference_baseline(scene_file):
+    """The REAL reference (oracle/_ref/ref_driver: the reference's own headers compiled in place with its own flags, built in
+    the build container, travels as a binary) timed on this box on BASELINE config 1 (200x200x16, threads = 1).  The rate is
+    the one the reference prints itself (renderer.h:700-706).  One thread by necessity: with threads > 1 its workers share
+    one unsynchronised mt19937 (random.h:9-15) and the image differs from run to run."""
+    import re
+    import tempfile
+    from oracle import pt_oracle, scene_params
+    if not pt_oracle.ref_available():
+        return None
+    try:
+        params = scene_params.load_scene_params(scene_file)
+        cfg = pt_oracle.make_config(200, 200, 16)
+        with tempfile.TemporaryDirectory() as d:
+            t0 = time.perf_counter()
+            txt = pt_oracle.ref_run(params, "render", pt_oracle._cfg_args(cfg) + [os.path.join(d, "fb.f32")], d)
+            wall = time.perf_counter() - t0
+        m = re.search(r"computed (\d+) rays, at ([0-9.eE+-]+) rays per second", txt)
+        t = re.search(r"time taken to compute ([0-9.eE+-]+)", txt)
+        rays = int(m.group(1))
+        return {"kind": "reference", "value": round(float(m.group(2)) / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                "cpu_model": cpu_model_name(), "nproc": os.cpu_count(),
+                "sample": f"scenes/{os.path.basename(scene_file)} 200x200x16 (BASELINE configs[0]), {rays} rays, the reference's own Tiled + NEEIterative "
+                          f"(oracle/_ref/ref_driver), render phase {float(t.group(1)) if t else wall:.2f} s, process {wall:.2f} s",
+                "rate_is": "the figure the reference prints (renderer.h:700-706: rays / time taken to compute)",
+                "single_threaded_because": "threads > 1 share one unsynchronised mt19937 (random.h:9-15): racy, the image differs per run, "
+                                           "and it scales 2.4x on 8 threads (SURVEY 8d)"}
+    except Exception as e:   # the headline number does not depend on it
+        return {"kind": "reference", "error": str(e)[:200]}
 
 
 def model_bytes(kernel, d):
@@ -154,7 +203,7 @@ def pmc_profile(dom):
             continue
         mk = d.get(dom)
         if d.get("kernel_source_sha16") == sha and mk:
-            out["valu"] = {"valu_per_wave": mk["valu_per_wave"], "salu_over_valu": mk["salu_over_valu"],
+            out["valu"] = {"valu_per_wave": mk["valu_per_wave"], "salu_over_valu": mk["salu_over_valu"], "issue_cycles_per_valu": mk.get("issue_cycles_per_valu"),
                            "wave_insts_per_s": mk["valu_insts_per_s"], "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS,
                            "frac": round(mk["valu_insts_per_s"] / VALU_PEAK_WAVE_INSTS, 4),
                            "source": "profiles/" + os.path.basename(f)}
@@ -162,7 +211,18 @@ def pmc_profile(dom):
     return out
 
 
-def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
+def sweep_label(spec_state, info):
+    """Which kernels traced, and who compiled them (pt_spec_info): a module built by a compiler other than the library's own
+    (an in-process fallback onto a PyTorch wheel's bundled hiprtc / comgr) is correct and measurably slower -- the line says so."""
+    if spec_state != 1:
+        return {"sweep": "generic kernels", "info": info}
+    foreign = info.get("own_compiler") is False
+    return {"sweep": "per-scene build" + (" (FOREIGN COMPILER)" if foreign else ""), "built_by": info.get("built_by"),
+            "rtc_lib": info.get("rtc_lib"), "producer": info.get("producer"), "own_compiler": info.get("own_compiler"),
+            "note": info.get("note")}
+
+
+def sub_config(pt, name, scene_file, w, h, spp_step, steps, device, oracle=None):
     """Another BASELINE configuration on this GPU: Mrays/s (unprofiled, `steps` steps), rays per camera sample, and the
     kernel times of a short serialised pass (one lane)."""
     scene = pt.Scene(os.path.join(ROOT, "scenes", scene_file), w, h)
@@ -191,13 +251,33 @@ def sub_config(pt, name, scene_file, w, h, spp_step, steps, device):
     r.wait()
     kt = r.kernel_times()
     dom = max(("extend", "shade", "connect"), key=lambda k: kt[k]["ms"])
+    r.set_profiling(False)
+    # parity with the metric, on the kernels that were just timed (this context's per-scene module): an 8 x 8 window in the
+    # middle of the frame at 16 spp against the oracle in stream mode, bit for bit, with its ray count
+    parity = None
+    if oracle is not None:
+        import numpy as np
+        wx, wy, pspp = (w // 2 - 4) & ~1, (h // 2 - 4) & ~1, 16
+        rect = (wx, wy, wx + 8, wy + 8)
+        r.clear()
+        r.render_async(0, pspp, rect)
+        gfb = r.framebuffer()[wy:wy + 8, wx:wx + 8]
+        gc = r.counters()
+        osc = oracle.Scene.from_json(os.path.join(ROOT, "scenes", scene_file))
+        ofb = np.zeros((h, w, 3), np.float32)
+        _, oc = osc.render_stream(oracle.make_config(w, h, pspp), seed=0, rect=rect, threads=2, fb=ofb)
+        ofb = ofb[wy:wy + 8, wx:wx + 8]
+        same = (gfb.view(np.uint32) == ofb.view(np.uint32)) | (gfb == ofb)
+        parity = {"window": list(rect), "spp": pspp, "mismatched": int((~same).sum()), "pixel_channels": int(same.size),
+                  "rays_equal": gc["rays"] == oc["rays"], "tolerance_ulp": 0}
+    info = r.spec_info()
     r.close()
     scene.close()
-    return {"config": name, "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp, {spp_launch} spp per launch",
+    return {"config": name, "parity": parity, "module": sweep_label(spec, info), "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp, {spp_launch} spp per launch",
             "value": round(c["rays_traced"] / dt / 1e6, 2), "value_reference_equivalent": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
             "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4),
             "traced_share": round(c["rays_traced"] / max(c["rays"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
-            "dominant_kernel": "k_" + dom, "sweep": "per-scene build" if spec == 1 else "generic",
+            "dominant_kernel": "k_" + dom, "sweep": sweep_label(spec, info)["sweep"],
             "kernel_ms_serialised_one_launch": {k: round(v["ms"], 3) for k, v in kt.items()}}
 
 
@@ -245,7 +325,7 @@ def main():
 
     weak = os.environ.get("PT_BENCH_SCALING") == "weak"
     scene = pt.Scene(args.scene, WIDTH, HEIGHT)
-    from pathtrace_amd.distributed import measure_tile_costs, reduce_framebuffer, tiles_for_rank
+    from pathtrace_amd.distributed import OwnedTileExchange, measure_tile_costs, reduce_framebuffer, tiles_for_rank
     spiral = pt.spiral_tiles(WIDTH, HEIGHT, TILE, TILE)
     costs = None
 
@@ -265,6 +345,12 @@ def main():
             costs = tile_costs()
         my_tiles = tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, rank, n, costs)
     setup_ms = (time.perf_counter() - setup_t0) * 1e3
+    # the one collective of the path: every rank's OWN tiles gathered into rank 0's framebuffer (index tensors and staging
+    # buffers built here, outside the timed region); PT_BENCH_EXCHANGE=reduce = a sum-reduce of whole frames instead
+    exchange = None
+    if n > 1 and os.environ.get("PT_BENCH_EXCHANGE", "gather") != "reduce":
+        lists = [tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, q, n, costs) for q in range(n)]
+        exchange = OwnedTileExchange(lists, WIDTH, HEIGHT, rank, n, torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
     #   strong (default): total work fixed -- K steps of 16 spp over the frame; each rank renders its 1/N of the pixels
     #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
     total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
@@ -274,6 +360,7 @@ def main():
     # pt_create started the per-scene build of the traversal kernels (hiprtc, ~2 s, like the scene upload outside the timed
     # region); wait for it so that every timed launch runs the same kernels.  -1: not available, the generic kernels run.
     spec_state = r.spec_wait()
+    spec_info = r.spec_info()
     # render straight into a torch tensor so that the final reduce needs no copy
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
@@ -292,18 +379,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def exchange_fb():
+        if dist is None:
+            return
+        if rehearsal:
+            fb_host = fb.cpu()
+            exchange.run(fb_host) if exchange else reduce_framebuffer(fb_host, dst=0)
+            fb.copy_(fb_host)
+        elif exchange:
+            exchange.run(fb)
+        else:
+            reduce_framebuffer(fb, dst=0)
+
     def timed_pass(spp):
         r.clear()
         sync()
         t0 = time.perf_counter()
         render_range(r, my_tiles, 0, spp, spp_launch)
         r.wait()
-        if rehearsal and dist is not None:
-            fb_host = fb.cpu()
-            reduce_framebuffer(fb_host, dst=0)
-            fb.copy_(fb_host)
-        else:
-            reduce_framebuffer(fb, dst=0)   # the one exchange of the path; no-op at N = 1
+        exchange_fb()   # the one exchange of the path; no-op at N = 1
         sync()
         return time.perf_counter() - t0
 
@@ -312,7 +406,7 @@ def main():
         render_range(r, my_tiles, 0, warm_spp, spp_launch)
     sync()
     if dist is not None and not rehearsal and args.warmup > 0:
-        reduce_framebuffer(fb, dst=0)   # untimed: RCCL sets its rings and kernels up on the first reduce of this shape
+        exchange_fb()   # untimed: RCCL sets its rings and kernels up on the first collective of this shape
         sync()
 
     # ---- the timed region: exactly K steps, per-launch profiling off ----
@@ -350,7 +444,7 @@ def main():
         ser = {}
         for k in ("generate", "extend", "shade", "connect", "accumulate"):
             ms, launches = kt_ser[k]["ms"], kt_ser[k]["launches"]
-            sb = stream_bytes(k, ctr_ser, 4, max(kt_ser["accumulate"]["launches"], 1), my_pixels, kt_ser["generate"]["launches"])
+            sb = stream_bytes(k, ctr_ser, LIGHT_SAMPLES, max(kt_ser["accumulate"]["launches"], 1), my_pixels, kt_ser["generate"]["launches"])
             mb = model_bytes(k, ctr_ser) if launches else 0   # no launch (k_generate: bounce 0 forms the camera rays), no bytes
             if k == "accumulate":
                 mb = sb   # the 8(d) model's 32 B framebuffer update per camera sample is per PASS here: one per pixel and launch, 16 B read per sample
@@ -361,16 +455,23 @@ def main():
         kernel_ms_sum = sum(v["ms"] for v in kt_ser.values())
         pmc = pmc_profile(dom)
         ser_rays = ctr_ser["rays_traced"]
+        avg_ms = kt_ser[dom]["ms"] / max(ser[dom]["launches"], 1)
         roofline = {"bound": "hbm", "kernel": "k_" + dom,
                     "achieved": ser[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ser[dom]["frac"],
                     "traffic": pmc["traffic_bytes_per_launch"],
-                    "avg_launch_ms": round(kt_ser[dom]["ms"] / max(ser[dom]["launches"], 1), 5), "launches": ser[dom]["launches"],
+                    "avg_launch_ms": round(avg_ms, 5), "launches": ser[dom]["launches"],
                     "bytes_per_launch_model": round(ser[dom]["model_bytes"] / max(ser[dom]["launches"], 1), 1),
-                    "how": "achieved = SURVEY 8d model bytes of the dominant kernel over its launches / their summed HIP-event time, "
-                           "both from the serialised pass below (one lane: the kernel has the chip to itself)",
+                    "how": "achieved / frac = SURVEY 8d ALGORITHMIC bytes of the dominant kernel over its launches / their summed HIP-event time "
+                           "(one-lane pass below: the kernel has the chip to itself).  The records this implementation moves are smaller than the "
+                           "model's (hbm_frac_stream), the counters agree with them (hbm_frac_counters), and the kernel is bound by vector-"
+                           "instruction issue, not by HBM: `bound` names the largest of issue_frac / hbm_frac_counters (or _stream)",
+                    "hbm_frac_model": ser[dom]["frac"],
+                    "hbm_frac_stream": round(ser[dom]["stream_GBps"] / HBM_PEAK_GBS, 4),
+                    "hbm_frac_counters": None, "issue_frac": None,
                     "serialised": {"steps": ser_spp // SPP_PER_STEP, "spp": ser_spp, "lanes": 1, "wall_ms": round(dt_ser * 1e3, 3),
                                    "kernel_ms_sum": round(kernel_ms_sum, 3), "kernels": ser,
                                    "pipeline_model_GBps": round(sum(v["model_bytes"] for v in ser.values()) / (kernel_ms_sum * 1e-3) / 1e9, 1) if kernel_ms_sum > 0 else None,
+                                   "pipeline_stream_GBps": round(sum(v["stream_bytes"] for v in ser.values()) / (kernel_ms_sum * 1e-3) / 1e9, 1) if kernel_ms_sum > 0 else None,
                                    "Mrays_per_s_traced": round(ser_rays / dt_ser / 1e6, 1)},
                     "overlapped": {"note": f"{N_LANES} batches in flight: launches share the chip, their event times overlap and sum to more than the wall time",
                                    "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items()},
@@ -379,13 +480,27 @@ def main():
                                    "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
                                    "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)},
                     "pmc": pmc}
-        if pmc["traffic_bytes_per_launch"] and roofline["avg_launch_ms"] > 0:
+        if pmc["traffic_bytes_per_launch"] and avg_ms > 0:
             # the counters' bytes per launch of the same build and batch size (one lane, like this pass) over this pass's launch time
-            g = pmc["traffic_bytes_per_launch"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+            g = pmc["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
             roofline["hbm_by_counters"] = {"GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_launch": pmc["traffic_bytes_per_launch"],
                                            "source": pmc["traffic_source"]}
-        if pmc["valu"] and pmc["valu"]["frac"] > roofline["frac"]:
-            roofline["bound"] = "valu"   # the vector-issue share of the same kernel (PMC pass of this build) exceeds its HBM share
+            roofline["hbm_frac_counters"] = round(g / HBM_PEAK_GBS, 4)
+        if pmc["valu"]:
+            # class-weighted issue model: the kernel's vector instructions per second (SQ_INSTS_VALU of the same-build
+            # PMC pass over its own time) x what an instruction of its static mix costs to issue / the chip's SIMD cycles per second
+            cyc = pmc["valu"].get("issue_cycles_per_valu")
+            if cyc:
+                roofline["issue_frac"] = round(pmc["valu"]["wave_insts_per_s"] * cyc / (SIMDS * CLOCK_HZ), 4)
+                roofline["issue_model"] = {"wave_insts_per_s": pmc["valu"]["wave_insts_per_s"], "issue_cycles_per_valu_inst": cyc,
+                                           "class_cycles": ISSUE_CYCLES, "simd_cycles_per_s": SIMDS * CLOCK_HZ, "source": pmc["valu"]["source"]}
+        hbm_real = roofline["hbm_frac_counters"] if roofline["hbm_frac_counters"] is not None else roofline["hbm_frac_stream"]
+        if roofline["issue_frac"] is not None:
+            roofline["bound"] = "valu-issue" if roofline["issue_frac"] >= hbm_real else "hbm"
+        else:
+            # no PMC pass of this build: the kernel moves hbm_real of the HBM roof by its own records; below half of it nothing
+            # is bandwidth-bound on this chip (a copy sustains 0.79 of spec) -- the remaining candidate is instruction issue
+            roofline["bound"] = "hbm" if hbm_real >= 0.6 else "valu-issue (inferred: no PMC pass of this build; the kernel's records move %.2f of the HBM roof)" % hbm_real
 
         # ---- strong-scaling proxy on this one GPU (the render has no communication: rank r's time here is rank r's time at N) ----
         proxy = None
@@ -432,11 +547,14 @@ def main():
         configs = None
         if n == 1 and not args.no_configs and not os.environ.get("PT_BENCH_SIZE"):
             configs = []
+            cfg_oracle = None
+            if not args.no_cpu_baseline:
+                from oracle import pt_oracle as cfg_oracle   # the checker of the sub-runs' parity windows
             for name, sf, w, h, spp, st in (("configs[2]", "cornell_box_small_lights.json", 1920, 1080, 16, 32),
                                             ("configs[3]", "cornell_box_with_volume.json", 1920, 1080, 16, 32),
                                             ("configs[4] frame, 1 GPU", "cornell_box.json", 3840, 2160, 4, 32)):
                 try:
-                    configs.append(sub_config(pt, name, sf, w, h, spp, st, local_rank))
+                    configs.append(sub_config(pt, name, sf, w, h, spp, st, local_rank, cfg_oracle))
                 except Exception as e:   # the headline number does not depend on these
                     configs.append({"config": name, "error": str(e)})
 
@@ -459,7 +577,8 @@ def main():
             m0 = time.perf_counter()
             _, mctr = osc_mt.render_mt(mcfg)
             mdt = time.perf_counter() - m0
-            cpu = {"value": round(octr["rays"] / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            cpu = {"value": round(octr["rays"] / cdt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(), "nproc": os.cpu_count(),
+                   "reference": reference_baseline(args.scene),
                    "sample": f"cornell_box {WIDTH}x{HEIGHT} x {spp_cpu} spp ({octr['rays']} rays, all of them traced: compare with "
                              f"value_reference_equivalent), oracle stream mode, {cores} threads, {cdt:.2f} s wall",
                    "reference_order_1thread": {"value": round(mctr["rays"] / mdt / 1e6, 3), "unit": "Mrays/s", "cores": 1,
@@ -505,9 +624,11 @@ def main():
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
                        "shadow_rays_traced_share": round(traced_shadow / max(S, 1), 4),
                        "framebuffer_sum": fb_sum,
-                       "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 RCCL reduce"),
+                       "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 collective"),
                        "partition_setup_ms": round(setup_ms, 1),
-                       "sweep": ("per-scene build of k_extend and k_connect (hiprtc at pt_create)" if os.environ.get("PATHTRACE_HIP_SPEC_CONNECT", "1")[:1] != "0" else "per-scene build of k_extend (hiprtc at pt_create), generic k_connect") if spec_state == 1 else "generic kernels",
+                       "sweep": sweep_label(spec_state, spec_info)["sweep"] + ((" of k_extend and k_connect (hiprtc at pt_create)" if os.environ.get("PATHTRACE_HIP_SPEC_CONNECT", "1")[:1] != "0" else " of k_extend (hiprtc at pt_create), generic k_connect") if spec_state == 1 else ""),
+                       "module": sweep_label(spec_state, spec_info),
+                       "exchange": None if n == 1 else ("gather of owned tiles: %d bytes to rank 0" % exchange.bytes_moved() if exchange else "sum-reduce of whole frames"),
                        "knobs": knobs},
             "roofline": roofline,
             "scaling_proxy": proxy,

@@ -447,6 +447,12 @@ static int spec_header_text(const pt_scene_desc *sc, std::string &out)
     out += line;
     snprintf(line, sizeof line, "#define PT_SPEC_GA %d\n", hp.geom_all ? 1 : 0);
     out += line;
+    {   // flat program: the root's ENTER is the only one (pt_kernels.hip world_hit_fast_rb drops the skip positions)
+        int enters = 0;
+        for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) enters += hp.ops[i].kind == OP_ENTER;
+        snprintf(line, sizeof line, "#define PT_SPEC_FLAT %d\n", (enters == 1 && hp.ops[hp.n_general + 1].kind == OP_ENTER) ? 1 : 0);
+        out += line;
+    }
     out += "static __device__ constexpr int kSpecW[PT_SPEC_N][32] = {\n";
     for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) {
         int32_t w[32];

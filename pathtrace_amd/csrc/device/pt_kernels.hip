@@ -78,6 +78,9 @@ namespace ptd {
 #ifndef PT_SKIP_NOOP_RADIANCE
 #define PT_SKIP_NOOP_RADIANCE 1   // radiance updates that cannot change a bit are not performed (0: the A/B)
 #endif
+#ifndef PT_FAST_RB
+#define PT_FAST_RB 1         // scenes of rects and boxes: the fast sweep with box faces in the global fold (world_hit_fast_rb); 0: world_hit_fast
+#endif
 #ifndef PT_FUSE_GENERATE
 #define PT_FUSE_GENERATE 1   // bounce 0 forms its camera rays itself, no k_generate launch (0: k_generate writes them, as before)
 #endif
@@ -914,6 +917,212 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
 }
 
 // ------------------------------------------------------------------------------------------------
+// The fast sweep of scenes of RECTS AND BOXES ONLY (GA = false: every BASELINE scene but the volume one), round 4.  Same
+// program, same preconditions and the same (t, id) as world_hit_fast above, bit for bit, with fewer and cheaper
+// instructions per leaf face -- the sweep is bound by vector-instruction issue, and of the ~78 issue cycles a face cost
+// (20 two-cycle FP32 operations, 8 four-cycle compares / selects / maxima) these go:
+//
+//  * Box faces join the GLOBAL fold.  box::hit is hittable_list::hit over six rects with a shrinking closest_so_far
+//    (primitive.h:232-256, hittable_list.h:21-38), and bvh_node::hit then keeps the box's result iff it is closer than the
+//    current one (bvh.h:36-66).  Both levels apply one rule -- the smallest t wins, the LATER candidate on equal t -- and that
+//    rule picks the same element whether the sequence is folded in one level or in two (all accepted t are ordered: no NaN
+//    reaches the fold, see below).  So a box face is folded like a rect leaf with id = instance * 8 + face, against the
+//    ray's current (cur_t, cur_id) instead of a per-box (closest, face) pair followed by a fold of the box: six selects, a
+//    compare and a maximum less per box and ray.
+//  * No v_div_fixup, no NaN tracker.  v_div_fixup only patches zero / infinite / NaN operands and quotients outside the
+//    normal range; with a finite numerator, a finite NON-ZERO denominator and the ranges of pt_fdiv.h's precondition it
+//    returns its first operand (for a zero numerator the quotient is a zero whose sign cannot matter: t = +-0 < t_min is
+//    rejected).  World-space direction components are non-zero (tame); a LOCAL direction component of a rotated leaf can
+//    cancel to exactly zero: its hardware reciprocal is then infinite and the refined reciprocal NaN, and 0 * that reciprocal
+//    turns the wave's tracker NaN -- one two-cycle operation per RECIPROCAL of a rotated leaf (not per quotient) -- and the wave
+//    repeats the query with the general sweep, which is also what the old tracker did with the only NaN a leaf can produce
+//    (0 / 0).  Without zero denominators no t is NaN or infinite.
+//  * No "t > t_max" term: t_max is FLT_MAX (integrator.h:193, 246) and t is finite.
+//  * No mask term in flat programs: a ray that missed the root's box (or an idle lane) starts with cur_t = -inf, and
+//    "t - cur_t > 0" then rejects every face; tree-shaped programs (more than PT_FLAT_MAX_INSTANCES instances) keep the
+//    skip position of world_hit_fast.
+// A face then costs 16 two-cycle operations and 6 four-cycle ones (~61 cycles).  Leaves whose data are outside the
+// unscaled division's precondition (DOp::slot bit 4) keep their IEEE divisions and the NaN tracker, like before.
+// ------------------------------------------------------------------------------------------------
+DEVI float fdiv_q_nofix(float n, float d, float r)
+{   // fdiv_q (pt_fdiv.h) without the final v_div_fixup: the same quotient for finite n, finite non-zero d inside the precondition
+    float q = n * r;
+    float rem = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(rem, r, q);
+}
+// One rect face of a leaf (a rect, or one side of a box) against ray state (cur_t, cur_id): rect::hit primitive.h:186-206 with
+// the closest-hit rule folded in.  PLANE as in rect_axes; num = plane - local origin's plane component; r = fdiv_rcp(dpl);
+// skip <= 0: the ray is not masked (tree programs pass skipf - pc, flat programs a constant).
+template <int PLANE, bool IEEE, bool SKIP>
+DEVI void face_fold(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float r, float skip, int id,
+                    float &cur_t, int &cur_id, float &chk)
+{
+    const float T_MIN = 0.001f;
+    float dx, dpl, dz;
+    rect_axes<PLANE>(Bl, dx, dpl, dz);
+    const float t = IEEE ? num / dpl : fdiv_q_nofix(num, dpl, r);
+    const float xh = ox + t * dx;
+    const float zh = oz + t * dz;
+    // reject iff t < t_min || xh < x0 || xh > x1 || zh < z0 || zh > z1 (primitive.h:193-205; NaN compares false: not rejected) or the
+    // current hit is strictly closer -- one maximum, decided by its sign
+    float e = fmaxf(fmaxf(T_MIN - t, t - cur_t), fmaxf(fmaxf(x0 - xh, xh - x1), fmaxf(z0 - zh, zh - z1)));
+    if (SKIP) e = fmaxf(e, skip);
+    const bool take = !(e > 0.0f);
+    cur_t = take ? t : cur_t;
+    cur_id = take ? id : cur_id;
+    if (IEEE) chk = __builtin_fmaf(0.0f, cur_t, chk);   // an accepted NaN t (0 / 0): the general sweep decides
+}
+template <int NR>
+DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], float (&out_t)[NR], int (&out_id)[NR])
+{
+    const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
+    v3 inv[NR];
+    float cur_t[NR], skipf[NR], chk = 0.0f;
+    int cur_id[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        inv[r] = V(fdiv(1.0f, B[r].x), fdiv(1.0f, B[r].y), fdiv(1.0f, B[r].z));   // aabb.h:38
+        cur_t[r] = lane_valid ? FLT_MAX : -INFINITY;
+        cur_id[r] = -1;
+        skipf[r] = 0.0f;
+    }
+#ifdef PT_SPEC_HEADER
+#define OPW(i) kSpecW[pc][(i)]
+    constexpr bool kFlat = PT_SPEC_FLAT != 0;   // one ENTER op (the root's): no skip positions
+#pragma unroll
+    for (int pc = 0; pc < PT_SPEC_N; ++pc) {
+#else
+    constexpr bool kFlat = false;               // decided per scene at run time: the skip term stays (one subtraction per face)
+    const DOp *__restrict__ prog = S.ops + S.ops_fast_off;
+    const int n_ops = S.n_ops_fast;
+#define OPW(i) ((i) < 16 ? w0[(i)] : w1[(i) - 16])
+    for (int pc = 0; pc < n_ops; ++pc) {
+        const i32x16 w0 = *reinterpret_cast<const i32x16 *>(&prog[pc]);
+        const i32x16 w1 = *(reinterpret_cast<const i32x16 *>(&prog[pc]) + 1);
+#endif
+        const int kind = OPW(0), op_a = OPW(1), pat = OPW(2) & 15;
+        const bool op_ieee = (OPW(2) & 16) != 0;    // this leaf's data are outside the unscaled division's precondition
+        const int op_id_base = op_a * 8;
+        const float pcf = __int_as_float(OPW(3));   // (float)pc, stored by the host (pt_context.cpp)
+#define OPF(i) __int_as_float(OPW(4 + (i)))
+        if (kind == OP_ENTER) {   // aabb::hit aabb.h:34-53, as in world_hit_fast
+            const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
+            const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
+            const float endf = OPF(6);             // (float)op_a
+            float in_max = 1.0f;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float ax = dx0 * inv[r].x, cx = dx1 * inv[r].x;
+                const float ay = dy0 * inv[r].y, cy = dy1 * inv[r].y;
+                const float az = dz0 * inv[r].z, cz = dz1 * inv[r].z;
+                const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
+                const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
+                const bool miss = tmax <= tmin;
+                if (kFlat) {
+                    // the root's box: a ray that misses it hits nothing -- cur_t = -inf makes "t - cur_t > 0" reject every face
+                    cur_t[r] = miss ? -INFINITY : cur_t[r];
+                    in_max = fminf(in_max, (cur_t[r] > 0.0f) ? 0.0f : 1.0f);
+                } else {
+                    skipf[r] = __int_as_float(max(__float_as_int(skipf[r]), miss ? __float_as_int(endf) : 0));
+                    in_max = fminf(in_max, (lane_valid ? skipf[r] : 1e9f) - pcf);
+                }
+            }
+#ifdef PT_SPEC_HEADER
+            if (op_a >= PT_SPEC_N && !__any(in_max <= 0.0f)) break;
+#else
+            if (!__any(in_max <= 0.0f)) pc = op_a - 1;   // no ray of the wave is inside this subtree: jump to its end
+#endif
+            continue;
+        }
+        const float m[12] = {OPF(0), OPF(1), OPF(2), OPF(3), OPF(4), OPF(5), OPF(6), OPF(7), OPF(8), OPF(9), OPF(10), OPF(11)};
+        const float q0[3] = {OPF(12), OPF(13), OPF(14)}, q1[3] = {OPF(15), OPF(16), OPF(17)};
+        v3 Al, Bl[NR];
+        xf_pat<NR>(pat, m, A, B, Al, Bl);
+        // a rotated leaf (pat != 1): a local direction component may have cancelled to exactly zero (world components cannot:
+        // tame).  Its reciprocal is then infinite and the refined one NaN: 0 * rc makes the tracker NaN for good, one two-cycle
+        // operation per reciprocal instead of the v_div_fixup of every quotient.
+        const bool rot = pat != 1;
+        float skip[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) skip[r] = kFlat ? 0.0f : skipf[r] - pcf;
+        // one body per (kind, division) runs, kind and op_ieee being wave-uniform; the empty volatile asm keeps hipcc from
+        // if-converting the bodies into "compute all, select" (it did: DESIGN.md 4.1)
+#define RECT_LEAF(PLANE, DPL, IEEE_)                                                                                        \
+        {                                                                                                                \
+            float ox, opl, oz;                                                                                           \
+            rect_axes<PLANE>(Al, ox, opl, oz);                                                                           \
+            const float num = q1[1] - opl;                                                                               \
+            _Pragma("unroll") for (int r = 0; r < NR; r++)                                                               \
+            {                                                                                                            \
+                const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].DPL);                                                     \
+                if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                                  \
+                face_fold<PLANE, IEEE_, !kFlat>(q0[0], q0[1], q0[2], q1[0], num, ox, oz, Bl[r], rc, skip[r], op_id_base, cur_t[r], cur_id[r], chk); \
+            }                                                                                                            \
+        }
+        // box::hit primitive.h:229-242: sides in the order XY(p0.z) XY(p1.z) YZ(p0.x) YZ(p1.x) XZ(p0.y) XZ(p1.y); the two sides of an
+        // axis divide by the same local direction component
+#define BOX_LEAF(IEEE_)                                                                                                  \
+        {   /* axis by axis, both sides of an axis for every ray: two numerators live at a time */                       \
+            {                                                                                                            \
+                const float n0 = q0[2] - Al.z, n1 = q1[2] - Al.z;                                                        \
+                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
+                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].z);                                                   \
+                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
+                    face_fold<0, IEEE_, !kFlat>(q0[0], q0[1], q1[0], q1[1], n0, Al.x, Al.y, Bl[r], rc, skip[r], op_id_base + 0, cur_t[r], cur_id[r], chk); \
+                    face_fold<0, IEEE_, !kFlat>(q0[0], q0[1], q1[0], q1[1], n1, Al.x, Al.y, Bl[r], rc, skip[r], op_id_base + 1, cur_t[r], cur_id[r], chk); \
+                }                                                                                                        \
+            }                                                                                                            \
+            {                                                                                                            \
+                const float n0 = q0[0] - Al.x, n1 = q1[0] - Al.x;                                                        \
+                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
+                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].x);                                                   \
+                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
+                    face_fold<2, IEEE_, !kFlat>(q0[1], q0[2], q1[1], q1[2], n0, Al.y, Al.z, Bl[r], rc, skip[r], op_id_base + 2, cur_t[r], cur_id[r], chk); \
+                    face_fold<2, IEEE_, !kFlat>(q0[1], q0[2], q1[1], q1[2], n1, Al.y, Al.z, Bl[r], rc, skip[r], op_id_base + 3, cur_t[r], cur_id[r], chk); \
+                }                                                                                                        \
+            }                                                                                                            \
+            {                                                                                                            \
+                const float n0 = q0[1] - Al.y, n1 = q1[1] - Al.y;                                                        \
+                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
+                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].y);                                                   \
+                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
+                    face_fold<1, IEEE_, !kFlat>(q0[0], q0[2], q1[0], q1[2], n0, Al.x, Al.z, Bl[r], rc, skip[r], op_id_base + 4, cur_t[r], cur_id[r], chk); \
+                    face_fold<1, IEEE_, !kFlat>(q0[0], q0[2], q1[0], q1[2], n1, Al.x, Al.z, Bl[r], rc, skip[r], op_id_base + 5, cur_t[r], cur_id[r], chk); \
+                }                                                                                                        \
+            }                                                                                                            \
+        }
+        if (kind == OP_LEAF_RECT_XY) { if (op_ieee) { asm volatile("; rect xy ieee"); RECT_LEAF(0, z, true) } else { asm volatile("; rect xy"); RECT_LEAF(0, z, false) } }
+        else if (kind == OP_LEAF_RECT_YZ) { if (op_ieee) { asm volatile("; rect yz ieee"); RECT_LEAF(2, x, true) } else { asm volatile("; rect yz"); RECT_LEAF(2, x, false) } }
+        else if (kind == OP_LEAF_RECT_XZ) { if (op_ieee) { asm volatile("; rect xz ieee"); RECT_LEAF(1, y, true) } else { asm volatile("; rect xz"); RECT_LEAF(1, y, false) } }
+        else if (kind == OP_LEAF_BOX) { if (op_ieee) { asm volatile("; box ieee"); BOX_LEAF(true) } else { asm volatile("; box fast"); BOX_LEAF(false) } }
+        // OP_LEAF_NONE: never a hit
+#undef BOX_LEAF
+#undef RECT_LEAF
+#undef OPF
+#undef OPW
+    }
+    if (S.n_chain) {   // flat program: the winner's parent box, per lane (see world_hit_fast)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const float4 *ch = S.chains + (size_t)max(cur_id[r] >> 3, 0) * 2;
+            const float4 lo = ch[0], hi = ch[1];
+            const v3 inv_r = inv[r];
+            const float ax = (lo.x - A.x) * inv_r.x, cx = (hi.x - A.x) * inv_r.x;
+            const float ay = (lo.y - A.y) * inv_r.y, cy = (hi.y - A.y) * inv_r.y;
+            const float az = (lo.z - A.z) * inv_r.z, cz = (hi.z - A.z) * inv_r.z;
+            const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), T_MIN);
+            const float tmax = fminf(fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz)), T_MAX);
+            chk = ((tmax <= tmin) && cur_id[r] >= 0) ? NAN : chk;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) { out_t[r] = (cur_id[r] >= 0) ? cur_t[r] : 0.0f; out_id[r] = cur_id[r]; }
+    return is_nanf(chk);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The WALK: World::hit for scenes of many instances (DScene::walk; the sweeps cost O(#ops) per ray whatever the ray
 // hits).  Every lane descends the bvh_node tree on its own -- node boxes and leaf records are per-lane loads, the pending
 // right children sit on a per-lane stack (the general sweep's short-stack area) -- in bvh_node::hit's order, left subtree
@@ -1035,7 +1244,13 @@ DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], u
             for (int r = 0; r < NR; r++) redo = world_hit_walk(S, lane_valid, A, B[r], k0, k1, vol_dim_base[r], stk, out_t[r], out_id[r]) || redo;
             general = __any(redo && lane_valid);
         } else
-        general = __any(world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id) && lane_valid);
+        {
+            // scenes of rects and boxes only take the round-4 form of the fast sweep (PT_FAST_RB=0: the A/B)
+            bool redo;
+            if constexpr (!GA && PT_FAST_RB) redo = world_hit_fast_rb<NR>(S, lane_valid, A, B, out_t, out_id);
+            else redo = world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
+            general = __any(redo && lane_valid);
+        }
 #ifdef PT_DBG_NO_REDO
         general = false;
 #endif

@@ -67,6 +67,50 @@ def test_tile_partition_and_reduce_world2(tmp_path, oracle, balanced):
     assert (got[..., 3] == 0).all()
 
 
+def _exchange_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pathtrace_amd.distributed import OwnedTileExchange, tiles_for_rank
+
+    w, h, tile = 200, 120, 32   # ragged edge tiles (200 = 6 x 32 + 8, 120 = 3 x 32 + 24)
+    lists = [tiles_for_rank(w, h, tile, tile, q, world) for q in range(world)]
+    ex = OwnedTileExchange(lists, w, h, rank, world, torch.device("cpu"))
+    # every rank fills ITS pixels with a value that names the pixel and the rank; foreign pixels hold garbage that must not travel
+    fb = torch.full((h, w, 4), -7.0 - rank, dtype=torch.float32)
+    flat = fb.view(-1, 4)
+    idx = ex.mine
+    flat[idx] = torch.stack([idx.float(), torch.full_like(idx, rank).float(), (idx % 13).float(), torch.zeros(len(idx))], dim=1)
+    ex.run(fb)
+    if rank == 0:
+        np.save(out_path, fb.numpy())
+        assert ex.bytes_moved() == sum(ex.counts[1:]) * 16 and sum(ex.counts) == w * h
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owned_tile_exchange_assembles_the_frame(tmp_path, world):
+    # bench.py's N > 1 exchange: every rank sends only the pixels of its tiles (one gather of 1/N-frame buffers), rank 0
+    # writes them in place -- the assembled frame holds every pixel's owner's value and nothing else
+    from pathtrace_amd.distributed import tiles_for_rank
+
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_exchange_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    w, h, tile = 200, 120, 32
+    owner = np.full((h, w), -1, np.int64)
+    for q in range(world):
+        for (x0, y0, x1, y1) in tiles_for_rank(w, h, tile, tile, q, world):
+            owner[y0:y1, x0:x1] = q
+    pix = np.arange(w * h, dtype=np.float32).reshape(h, w)
+    assert (owner >= 0).all()
+    assert np.array_equal(got[..., 0], pix) and np.array_equal(got[..., 1], owner.astype(np.float32))
+    assert np.array_equal(got[..., 2], (np.arange(w * h) % 13).astype(np.float32).reshape(h, w)) and (got[..., 3] == 0).all()
+
+
 def test_tile_ownership_is_a_partition():
     from pathtrace_amd.distributed import tiles_for_rank
 

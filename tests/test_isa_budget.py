@@ -16,8 +16,12 @@ VALU = ("fp2", "fp2s", "v4", "pk", "trans")
 # kernel -> (min occupancy, max static VALU instructions, max basic block, max scalar instructions, max spilled VGPRs,
 #            max spilled SGPRs: a spilled SGPR is a v_writelane / v_readlane pair through a VGPR the kernel then cannot use)
 BUDGET = {
-    "void ptd::k_extend<false, false, false>": (7, 1180, 220, 545, 0, 12),
-    "void ptd::k_connect<2, false, false, false>": (6, 2800, 370, 825, 0, 45),
+    # round 4 (world_hit_fast_rb): every leaf body carries its own fold now (no shared tail), so the STATIC total rose by the
+    # duplicated folds while the path through one body got shorter (rect 31, box side ~27 vector instructions)
+    "void ptd::k_extend<false, false, false>": (7, 1300, 220, 560, 0, 12),
+    # round 4: box faces fold into the ray's (t, id) directly (world_hit_fast_rb); the generic loop keeps two lane values of its
+    # prologue in scratch (the per-scene build, which production runs, is checked by tools/spec_isa.py / test_spec_isa_budget)
+    "void ptd::k_connect<2, false, false, false>": (6, 2950, 420, 840, 2, 45),
     # a few loop-invariant lane values of the prologue live in scratch: one reload each per 256-path chunk; the static counts
     # hold three copies of the light-sample loop (one per rect alignment, one of them runs)
     "void ptd::k_shade<false, 1, true, false>": (6, 3550, 330, 1560, 4, 120),
