@@ -497,10 +497,13 @@ def main():
         hbm_real = roofline["hbm_frac_counters"] if roofline["hbm_frac_counters"] is not None else roofline["hbm_frac_stream"]
         if roofline["issue_frac"] is not None:
             roofline["bound"] = "valu-issue" if roofline["issue_frac"] >= hbm_real else "hbm"
+            roofline["bound_basis"] = "issue_frac %.2f against %.2f of the HBM roof (%s)" % (
+                roofline["issue_frac"], hbm_real, "counters" if roofline["hbm_frac_counters"] is not None else "this implementation's record bytes")
         else:
-            # no PMC pass of this build: the kernel moves hbm_real of the HBM roof by its own records; below half of it nothing
-            # is bandwidth-bound on this chip (a copy sustains 0.79 of spec) -- the remaining candidate is instruction issue
-            roofline["bound"] = "hbm" if hbm_real >= 0.6 else "valu-issue (inferred: no PMC pass of this build; the kernel's records move %.2f of the HBM roof)" % hbm_real
+            # no PMC pass of this build: the kernel moves hbm_real of the HBM roof by its own records; below 0.6 of it nothing is
+            # bandwidth-bound on this chip (a copy sustains 0.79 of spec) -- the remaining candidate is instruction issue
+            roofline["bound"] = "hbm" if hbm_real >= 0.6 else "valu-issue"
+            roofline["bound_basis"] = "inferred (no PMC pass of this build of the kernels): the kernel's own records move %.2f of the HBM roof" % hbm_real
 
         # ---- strong-scaling proxy on this one GPU (the render has no communication: rank r's time here is rank r's time at N) ----
         proxy = None

@@ -78,6 +78,21 @@ namespace ptd {
 #ifndef PT_SKIP_NOOP_RADIANCE
 #define PT_SKIP_NOOP_RADIANCE 1   // radiance updates that cannot change a bit are not performed (0: the A/B)
 #endif
+#ifndef PT_LIGHT_UNROLL
+#define PT_LIGHT_UNROLL 1    // k_shade's light-sample loop of the one-rect-light case: samples in flight per iteration (measurement knob)
+#endif
+#define PT_LIGHT_ONE(P, k_) rect_light_sample(PlaneTag<P>{}, (k_), base + NV + (k_) * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y)
+#if PT_LIGHT_UNROLL == 2   // two samples per iteration (independent chains side by side), a last one for odd counts
+#define PT_LIGHT_LOOP(P) { uint32_t k = 0; for (; k + 1 < L; k += 2) { PT_LIGHT_ONE(P, k); PT_LIGHT_ONE(P, k + 1); } if (k < L) PT_LIGHT_ONE(P, k); }
+#else
+#define PT_LIGHT_LOOP(P) for (uint32_t k = 0; k < L; k++) PT_LIGHT_ONE(P, k);
+#endif
+#ifndef PT_PK_DIV
+#define PT_PK_DIV 1          // world_hit_fast_rb: the two sides of a box axis divide on packed FP32 (0: one quotient at a time)
+#endif
+#ifndef PT_SYM_BOUNDS
+#define PT_SYM_BOUNDS 1      // per-scene build: faces centred on the local origin test |xh| - x1 instead of two differences (0: the A/B)
+#endif
 #ifndef PT_FAST_RB
 #define PT_FAST_RB 1         // scenes of rects and boxes: the fast sweep with box faces in the global fold (world_hit_fast_rb); 0: world_hit_fast
 #endif
@@ -955,24 +970,65 @@ DEVI float fdiv_q_nofix(float n, float d, float r)
 // One rect face of a leaf (a rect, or one side of a box) against ray state (cur_t, cur_id): rect::hit primitive.h:186-206 with
 // the closest-hit rule folded in.  PLANE as in rect_axes; num = plane - local origin's plane component; r = fdiv_rcp(dpl);
 // skip <= 0: the ray is not masked (tree programs pass skipf - pc, flat programs a constant).
+// the closest-hit rule on one rect face given its quotient t (see face_fold)
 template <int PLANE, bool IEEE, bool SKIP>
-DEVI void face_fold(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float r, float skip, int id,
-                    float &cur_t, int &cur_id, float &chk)
+DEVI void face_fold_t(float x0, float z0, float x1, float z1, float t, float ox, float oz, v3 Bl, float skip, int id,
+                      float &cur_t, int &cur_id, float &chk)
 {
     const float T_MIN = 0.001f;
     float dx, dpl, dz;
     rect_axes<PLANE>(Bl, dx, dpl, dz);
-    const float t = IEEE ? num / dpl : fdiv_q_nofix(num, dpl, r);
     const float xh = ox + t * dx;
     const float zh = oz + t * dz;
     // reject iff t < t_min || xh < x0 || xh > x1 || zh < z0 || zh > z1 (primitive.h:193-205; NaN compares false: not rejected) or the
     // current hit is strictly closer -- one maximum, decided by its sign
-    float e = fmaxf(fmaxf(T_MIN - t, t - cur_t), fmaxf(fmaxf(x0 - xh, xh - x1), fmaxf(z0 - zh, zh - z1)));
+    float ex, ez;
+#if defined(PT_SPEC_HEADER) && PT_SYM_BOUNDS
+    // Bounds symmetric about the local origin (x0 == -x1: every rect and box the scene format centres, scene_parser.h:131-170;
+    // a compile-time fact of the per-scene build): max(x0 - xh, xh - x1) and |xh| - x1 have the same sign for every xh -- for
+    // xh >= 0 the first term -(x1 + xh) is not positive and the second IS |xh| - x1, for xh < 0 the roles swap; NaN stays NaN
+    // (ignored by the maximum either way) -- and only the sign of the maximum is used.  One subtraction per axis instead of two.
+    if (x0 == -x1) ex = fabsf(xh) - x1; else ex = fmaxf(x0 - xh, xh - x1);
+    if (z0 == -z1) ez = fabsf(zh) - z1; else ez = fmaxf(z0 - zh, zh - z1);
+#else
+    ex = fmaxf(x0 - xh, xh - x1); ez = fmaxf(z0 - zh, zh - z1);
+#endif
+    float e = fmaxf(fmaxf(T_MIN - t, t - cur_t), fmaxf(ex, ez));
     if (SKIP) e = fmaxf(e, skip);
     const bool take = !(e > 0.0f);
     cur_t = take ? t : cur_t;
     cur_id = take ? id : cur_id;
     if (IEEE) chk = __builtin_fmaf(0.0f, cur_t, chk);   // an accepted NaN t (0 / 0): the general sweep decides
+}
+template <int PLANE, bool IEEE, bool SKIP>
+DEVI void face_fold(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float r, float skip, int id,
+                    float &cur_t, int &cur_id, float &chk)
+{
+    float dx, dpl, dz;
+    rect_axes<PLANE>(Bl, dx, dpl, dz);
+    const float t = IEEE ? num / dpl : fdiv_q_nofix(num, dpl, r);
+    face_fold_t<PLANE, IEEE, SKIP>(x0, z0, x1, z1, t, ox, oz, Bl, skip, id, cur_t, cur_id, chk);
+}
+// The two sides of a box axis divide their numerators by ONE denominator: both quotients at once on packed FP32
+// (v_pk_mul_f32 / v_pk_fma_f32: two individually rounded IEEE operations per instruction -- a plain v_fma_f32 occupies the SIMD as
+// long as the packed one, tools/microbench/valu_rates.hip -- the scalars d and r enter through op_sel, no moves).  Per
+// component it is fdiv_q_nofix statement for statement.
+typedef float pt_pk2 __attribute__((ext_vector_type(2)));
+DEVI void fdiv_q2_nofix(float n0, float n1, float d, float r, float &q0, float &q1)
+{
+#if PT_PK_DIV
+    pt_pk2 n; n.x = n0; n.y = n1;
+    pt_pk2 dd; dd.x = d; dd.y = d;
+    pt_pk2 rr; rr.x = r; rr.y = r;
+    pt_pk2 q = n * rr;
+    pt_pk2 rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    q0 = q.x; q1 = q.y;
+#else
+    q0 = fdiv_q_nofix(n0, d, r); q1 = fdiv_q_nofix(n1, d, r);
+#endif
 }
 template <int NR>
 DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], float (&out_t)[NR], int (&out_id)[NR])
@@ -1063,35 +1119,26 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
         }
         // box::hit primitive.h:229-242: sides in the order XY(p0.z) XY(p1.z) YZ(p0.x) YZ(p1.x) XZ(p0.y) XZ(p1.y); the two sides of an
         // axis divide by the same local direction component
+#define BOX_AXIS(IEEE_, PLANE, DPL, X0, Z0, X1, Z1, N0, N1, OX, OZ, F0)                                                    \
+            {                                                                                                            \
+                const float n0 = (N0), n1 = (N1);                                                                        \
+                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
+                    float t0, t1;                                                                                        \
+                    if (IEEE_) { t0 = n0 / Bl[r].DPL; t1 = n1 / Bl[r].DPL; }                                             \
+                    else {                                                                                               \
+                        const float rc = fdiv_rcp(Bl[r].DPL);                                                            \
+                        if (rot) chk = __builtin_fmaf(0.0f, rc, chk);                                                    \
+                        fdiv_q2_nofix(n0, n1, Bl[r].DPL, rc, t0, t1);                                                    \
+                    }                                                                                                    \
+                    face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t0, OX, OZ, Bl[r], skip[r], op_id_base + (F0), cur_t[r], cur_id[r], chk);     \
+                    face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t1, OX, OZ, Bl[r], skip[r], op_id_base + (F0) + 1, cur_t[r], cur_id[r], chk); \
+                }                                                                                                        \
+            }
 #define BOX_LEAF(IEEE_)                                                                                                  \
         {   /* axis by axis, both sides of an axis for every ray: two numerators live at a time */                       \
-            {                                                                                                            \
-                const float n0 = q0[2] - Al.z, n1 = q1[2] - Al.z;                                                        \
-                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
-                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].z);                                                   \
-                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
-                    face_fold<0, IEEE_, !kFlat>(q0[0], q0[1], q1[0], q1[1], n0, Al.x, Al.y, Bl[r], rc, skip[r], op_id_base + 0, cur_t[r], cur_id[r], chk); \
-                    face_fold<0, IEEE_, !kFlat>(q0[0], q0[1], q1[0], q1[1], n1, Al.x, Al.y, Bl[r], rc, skip[r], op_id_base + 1, cur_t[r], cur_id[r], chk); \
-                }                                                                                                        \
-            }                                                                                                            \
-            {                                                                                                            \
-                const float n0 = q0[0] - Al.x, n1 = q1[0] - Al.x;                                                        \
-                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
-                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].x);                                                   \
-                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
-                    face_fold<2, IEEE_, !kFlat>(q0[1], q0[2], q1[1], q1[2], n0, Al.y, Al.z, Bl[r], rc, skip[r], op_id_base + 2, cur_t[r], cur_id[r], chk); \
-                    face_fold<2, IEEE_, !kFlat>(q0[1], q0[2], q1[1], q1[2], n1, Al.y, Al.z, Bl[r], rc, skip[r], op_id_base + 3, cur_t[r], cur_id[r], chk); \
-                }                                                                                                        \
-            }                                                                                                            \
-            {                                                                                                            \
-                const float n0 = q0[1] - Al.y, n1 = q1[1] - Al.y;                                                        \
-                _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
-                    const float rc = IEEE_ ? 0.0f : fdiv_rcp(Bl[r].y);                                                   \
-                    if (!IEEE_ && rot) chk = __builtin_fmaf(0.0f, rc, chk);                                              \
-                    face_fold<1, IEEE_, !kFlat>(q0[0], q0[2], q1[0], q1[2], n0, Al.x, Al.z, Bl[r], rc, skip[r], op_id_base + 4, cur_t[r], cur_id[r], chk); \
-                    face_fold<1, IEEE_, !kFlat>(q0[0], q0[2], q1[0], q1[2], n1, Al.x, Al.z, Bl[r], rc, skip[r], op_id_base + 5, cur_t[r], cur_id[r], chk); \
-                }                                                                                                        \
-            }                                                                                                            \
+            BOX_AXIS(IEEE_, 0, z, q0[0], q0[1], q1[0], q1[1], q0[2] - Al.z, q1[2] - Al.z, Al.x, Al.y, 0)                  \
+            BOX_AXIS(IEEE_, 2, x, q0[1], q0[2], q1[1], q1[2], q0[0] - Al.x, q1[0] - Al.x, Al.y, Al.z, 2)                  \
+            BOX_AXIS(IEEE_, 1, y, q0[0], q0[2], q1[0], q1[2], q0[1] - Al.y, q1[1] - Al.y, Al.x, Al.z, 4)                  \
         }
         if (kind == OP_LEAF_RECT_XY) { if (op_ieee) { asm volatile("; rect xy ieee"); RECT_LEAF(0, z, true) } else { asm volatile("; rect xy"); RECT_LEAF(0, z, false) } }
         else if (kind == OP_LEAF_RECT_YZ) { if (op_ieee) { asm volatile("; rect yz ieee"); RECT_LEAF(2, x, true) } else { asm volatile("; rect yz"); RECT_LEAF(2, x, false) } }
@@ -1099,6 +1146,7 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
         else if (kind == OP_LEAF_BOX) { if (op_ieee) { asm volatile("; box ieee"); BOX_LEAF(true) } else { asm volatile("; box fast"); BOX_LEAF(false) } }
         // OP_LEAF_NONE: never a hit
 #undef BOX_LEAF
+#undef BOX_AXIS
 #undef RECT_LEAF
 #undef OPF
 #undef OPW
@@ -2190,9 +2238,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     const DRect &lq = lpr.r[0];
                     const v3 tl = V(lin.inv[3], lin.inv[7], lin.inv[11]);
                     // one loop per alignment (wave-uniform branch); the empty asm keeps the three bodies apart
-                    if (lq.plane == 0) { asm volatile("; rect light xy"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<0>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
-                    else if (lq.plane == 2) { asm volatile("; rect light yz"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<2>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
-                    else { asm volatile("; rect light xz"); for (uint32_t k = 0; k < L; k++) rect_light_sample(PlaneTag<1>{}, k, base + NV + k * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y); }
+                    if (lq.plane == 0) { asm volatile("; rect light xy"); PT_LIGHT_LOOP(0) }
+                    else if (lq.plane == 2) { asm volatile("; rect light yz"); PT_LIGHT_LOOP(2) }
+                    else { asm volatile("; rect light xz"); PT_LIGHT_LOOP(1) }
                 } else {
                     for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, lpr, tr);
                 }
@@ -2477,10 +2525,16 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
 // ------------------------------------------------------------------------------------------------
 // at most 4096 workgroups per launch (256 CUs x 8 resident x 2: measured better balanced than 2048), few enough to dispatch quickly
 static int g_grid_max = 0;
-static int persistent_grid(long long chunks)
+static int g_grid_kernel[3] = {0, 0, 0};   // extend, shade, connect: PATHTRACE_HIP_GRID_EXTEND / _SHADE / _CONNECT (measurement knobs), 0 = PATHTRACE_HIP_GRID
+static int persistent_grid(long long chunks, int kernel = -1)
 {
-    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096; }
-    return (int)(chunks < g_grid_max ? chunks : g_grid_max);
+    if (!g_grid_max) {
+        const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096;
+        const char *names[3] = {"PATHTRACE_HIP_GRID_EXTEND", "PATHTRACE_HIP_GRID_SHADE", "PATHTRACE_HIP_GRID_CONNECT"};
+        for (int k = 0; k < 3; k++) { const char *v = getenv(names[k]); g_grid_kernel[k] = v ? atoi(v) : 0; }
+    }
+    const int cap = (kernel >= 0 && g_grid_kernel[kernel] > 0) ? g_grid_kernel[kernel] : g_grid_max;
+    return (int)(chunks < cap ? chunks : cap);
 }
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
@@ -2489,7 +2543,7 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s, SpecJob *spec)
 {
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK), 0)), block(PT_BLOCK);
     // the scene's own build of the sweep when it is ready (pt_spec.cpp), else -- and on any launch error -- the generic kernel
     if (spec && !S.walk && spec_launch_extend(spec, PT_FUSE_GENERATE && bounce == 0, (int)grid.x, lds, s, S, st, b, qi, bounce) == 0) return;
 #define PT_LAUNCH_EXTEND_B(GA, WALK, B0) hipLaunchKernelGGL((k_extend<GA, WALK, B0>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
@@ -2502,7 +2556,7 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK), 1)), block(PT_BLOCK);
     const size_t lds = b.stage_shadow ? (size_t)S.light_samples * PT_BLOCK * (sizeof(float4) + sizeof(float2)) : 0;
 #define PT_LAUNCH_SHADE_B(TEX, LM, B0)                                                                                                   \
     do {                                                                                                                                \
@@ -2532,7 +2586,7 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     if (!spec_connect) spec = nullptr;
     if (spec && !S.walk && L % spec_connect_nr(spec) == 0) nr = spec_connect_nr(spec);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
-    const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK), 2)), block(PT_BLOCK);
     if (spec && !S.walk && nr == spec_connect_nr(spec) && spec_launch_connect(spec, (int)grid.x, lds, s, S, st, b, bounce) == 0) return;
 #define PT_LAUNCH_CONNECT(NR, TEX, GA, WALK) hipLaunchKernelGGL((k_connect<NR, TEX, GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
 #define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA, false); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA, false); else PT_LAUNCH_CONNECT(1, TEX, GA, false); }

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 def run_bench(args, env_extra):
     env = dict(os.environ, **env_extra)
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    env.pop("PATHTRACE_HIP_SPEC", None)   # conftest switches the per-scene build off for the suite; bench.py runs as the driver runs it
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -32,7 +33,10 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank():
     for k in ("spp_total", "camera_samples", "rays", "framebuffer_sum"):
         assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
     for d in (one, two):
-        assert d["roofline"]["bound"] in ("hbm", "valu") and d["value"] > 0 and d["steps"] == 4
+        assert d["roofline"]["bound"] in ("hbm", "valu-issue") and d["roofline"]["bound_basis"] and d["value"] > 0 and d["steps"] == 4
+        # the fractions the label is chosen from, side by side: the contract's model bytes, this implementation's record bytes
+        assert 0 < d["roofline"]["hbm_frac_stream"] <= d["roofline"]["hbm_frac_model"] * 1.5 and d["roofline"]["frac"] == d["roofline"]["hbm_frac_model"]
+        assert d["config"]["module"]["sweep"].startswith("per-scene build") and d["config"]["module"]["own_compiler"] is True, d["config"]["module"]
         # value = rays the device traced; the reference's count for the same image is reported beside it
         assert d["value"] <= d["value_reference_equivalent"] and d["config"]["rays_traced"] <= d["config"]["rays"]
         ser = d["roofline"]["serialised"]

@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned useed)
     const double db = b;
 #define R8F(ins) asm volatile(ins : "+v"(a0) : "v"(b)); asm volatile(ins : "+v"(a1) : "v"(b)); asm volatile(ins : "+v"(a2) : "v"(b)); asm volatile(ins : "+v"(a3) : "v"(b)); \
                  asm volatile(ins : "+v"(a4) : "v"(b)); asm volatile(ins : "+v"(a5) : "v"(b)); asm volatile(ins : "+v"(a6) : "v"(b)); asm volatile(ins : "+v"(a7) : "v"(b));
+#define R8FC(ins, ...) asm volatile(ins : "+v"(a0) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a1) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a2) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a3) : "v"(b) : __VA_ARGS__); \
+                 asm volatile(ins : "+v"(a4) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a5) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a6) : "v"(b) : __VA_ARGS__); asm volatile(ins : "+v"(a7) : "v"(b) : __VA_ARGS__);
 #define R8U(ins) asm volatile(ins : "+v"(u0) : "v"(ub)); asm volatile(ins : "+v"(u1) : "v"(ub)); asm volatile(ins : "+v"(u2) : "v"(ub)); asm volatile(ins : "+v"(u3) : "v"(ub)); \
                  asm volatile(ins : "+v"(u4) : "v"(ub)); asm volatile(ins : "+v"(u5) : "v"(ub)); asm volatile(ins : "+v"(u6) : "v"(ub)); asm volatile(ins : "+v"(u7) : "v"(ub));
 #define R8D(ins) asm volatile(ins : "+v"(d0) : "v"(db)); asm volatile(ins : "+v"(d1) : "v"(db)); asm volatile(ins : "+v"(d2) : "v"(db)); asm volatile(ins : "+v"(d3) : "v"(db)); \
@@ -61,6 +63,27 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned useed)
                                          : : "v"(u0), "v"(ub) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "vcc"); }
         else if (OP == 27) { R8U("v_mul_hi_u32 %0, %0, %1") }
         else if (OP == 28) { R8F("v_frexp_exp_i32_f32 %0, %0") }
+        // round 4: packed FP32 (two results per lane), the two-operand maximum, selects, modifiers
+        else if (OP == 29) { asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[56:57], v[56:57]\n v_pk_fma_f32 v[42:43], v[42:43], v[56:57], v[56:57]\n v_pk_fma_f32 v[44:45], v[44:45], v[56:57], v[56:57]\n v_pk_fma_f32 v[46:47], v[46:47], v[56:57], v[56:57]\n"
+                                         "v_pk_fma_f32 v[48:49], v[48:49], v[56:57], v[56:57]\n v_pk_fma_f32 v[50:51], v[50:51], v[56:57], v[56:57]\n v_pk_fma_f32 v[52:53], v[52:53], v[56:57], v[56:57]\n v_pk_fma_f32 v[54:55], v[54:55], v[56:57], v[56:57]"
+                                         : : : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"); }
+        else if (OP == 30) { asm volatile("v_pk_mul_f32 v[40:41], v[40:41], v[56:57]\n v_pk_mul_f32 v[42:43], v[42:43], v[56:57]\n v_pk_mul_f32 v[44:45], v[44:45], v[56:57]\n v_pk_mul_f32 v[46:47], v[46:47], v[56:57]\n"
+                                         "v_pk_mul_f32 v[48:49], v[48:49], v[56:57]\n v_pk_mul_f32 v[50:51], v[50:51], v[56:57]\n v_pk_mul_f32 v[52:53], v[52:53], v[56:57]\n v_pk_mul_f32 v[54:55], v[54:55], v[56:57]"
+                                         : : : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"); }
+        else if (OP == 31) { asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[42:43], v[42:43], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[44:45], v[44:45], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[46:47], v[46:47], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n"
+                                         "v_pk_fma_f32 v[48:49], v[48:49], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[50:51], v[50:51], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[52:53], v[52:53], v[56:57], v[56:57] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[54:55], v[54:55], v[56:57], v[56:57] op_sel_hi:[1,0,0]"
+                                         : : : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55"); }
+        else if (OP == 32) { R8F("v_max_f32 %0, %0, %1") }
+        else if (OP == 33) { R8F("v_add_f32 %0, %0, %1") }
+        else if (OP == 34) { R8F("v_sub_f32 %0, 0x40490fdb, %0") }
+        else if (OP == 35) { R8F("v_sub_f32_e64 %0, |%0|, s4") }
+        else if (OP == 36) { R8F("v_cndmask_b32_e32 %0, %0, %1, vcc") }
+        else if (OP == 37) { R8F("v_max3_f32 %0, |%0|, %1, %1") }
+        else if (OP == 38) { R8F("v_fma_f32 %0, %0, %1, %0") }
+        else if (OP == 39) { R8F("v_fmac_f32 %0, %1, %1") }
+        else if (OP == 40) { R8F("v_and_or_b32 %0, %0, %1, %1") }
+        else if (OP == 41) { R8F("v_med3_f32 %0, %0, %1, %1") }
+        else if (OP == 42) { R8F("v_min_u32 %0, %0, %1") }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
 }
@@ -89,16 +112,19 @@ int main()
     const char *names[] = {"v_fma_f32", "v_mul_f32", "v_mul_lo_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_xor_b32", "v_lshrrev_b32", "v_rcp_f32", "v_sqrt_f32",
                            "v_div_fixup_f32", "v_max3_f32", "v_cndmask_b32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_ldexp_f64", "v_cvt_f64_u32",
                            "v_cvt_f32_f64", "v_cvt_f32_u32", "v_readlane_b32", "v_div_scale_f32", "v_div_fmas_f32", "v_cmp_gt_f32", "v_mul_f32 sgpr", "v_mul_f32 literal",
-                           "v_mad_u64_u32", "v_mul_hi_u32", "v_frexp_exp_i32_f32"};
-    double ms[29];
+                           "v_mad_u64_u32", "v_mul_hi_u32", "v_frexp_exp_i32_f32",
+                           "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_fma_f32 op_sel splat", "v_max_f32", "v_add_f32", "v_sub_f32 literal", "v_sub_f32 |v| sgpr", "v_cndmask_b32 e32",
+                           "v_max3_f32 |v|", "v_fma_f32 2 regs", "v_fmac_f32", "v_and_or_b32", "v_med3_f32", "v_min_u32",
+                           "v_cndmask_b32 e64 sgpr", "v_cmp+v_cndmask vcc (2)", "v_cmp+v_cndmask sgpr (2)", "v_cmp+2 v_cndmask (3)", "v_mov_b32"};
+    double ms[48];
 #define RUN(i) ms[i] = run<i>(d_out, blocks);
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20)
-    RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28)
+    RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37) RUN(38) RUN(39) RUN(40) RUN(41) RUN(42) RUN(43) RUN(44) RUN(45) RUN(46) RUN(47)
     // per SIMD: (blocks * 4 waves / 1024 SIMDs) waves x ITER x 8 instructions
     const double per_simd = (double)blocks * 4 / 1024 * ITER * 8;
     const double ns_fma = ms[0] * 1e6 / per_simd;
     printf("{\"waves_per_simd\": %d, \"assumed_v_fma_f32_cycles\": 4, \"ns_per_v_fma_f32\": %.4f, \"implied_clock_GHz\": %.3f, \"cycles\": {", blocks * 4 / 1024, ns_fma, 4.0 / ns_fma);
-    for (int i = 0; i < 29; i++) printf("%s\"%s\": %.2f", i ? ", " : "", names[i], ms[i] * 1e6 / per_simd / ns_fma * 4.0);
+    for (int i = 0; i < 48; i++) printf("%s\"%s\": %.2f", i ? ", " : "", names[i], ms[i] * 1e6 / per_simd / ns_fma * 4.0);
     printf("}}\n");
     return 0;
 }
