@@ -84,6 +84,13 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, unsigned useed)
         else if (OP == 40) { R8F("v_and_or_b32 %0, %0, %1, %1") }
         else if (OP == 41) { R8F("v_med3_f32 %0, %0, %1, %1") }
         else if (OP == 42) { R8F("v_min_u32 %0, %0, %1") }
+        else if (OP == 43) { R8FC("v_cndmask_b32_e64 %0, %0, %1, s[60:61]", "s60", "s61") }
+        else if (OP == 44) { R8FC("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc", "vcc") }   // two instructions per instance
+        else if (OP == 45) { R8FC("v_cmp_gt_f32 s[60:61], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[60:61]", "s60", "s61") }
+        else if (OP == 46) { R8FC("v_cmp_gt_f32 vcc, %0, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %0, %1, %0, vcc", "vcc") }   // three
+        else if (OP == 47) { R8F("v_mov_b32 %0, %1") }
+        else if (OP == 48) { R8FC("v_cndmask_b32_e32 %0, %1, %0, vcc", "vcc") }
+        else if (OP == 49) { R8F("v_bfi_b32 %0, %0, %1, %1") }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7) + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
 }
@@ -115,16 +122,16 @@ int main()
                            "v_mad_u64_u32", "v_mul_hi_u32", "v_frexp_exp_i32_f32",
                            "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_fma_f32 op_sel splat", "v_max_f32", "v_add_f32", "v_sub_f32 literal", "v_sub_f32 |v| sgpr", "v_cndmask_b32 e32",
                            "v_max3_f32 |v|", "v_fma_f32 2 regs", "v_fmac_f32", "v_and_or_b32", "v_med3_f32", "v_min_u32",
-                           "v_cndmask_b32 e64 sgpr", "v_cmp+v_cndmask vcc (2)", "v_cmp+v_cndmask sgpr (2)", "v_cmp+2 v_cndmask (3)", "v_mov_b32"};
-    double ms[48];
+                           "v_cndmask_b32 e64 sgpr", "v_cmp+v_cndmask vcc (2)", "v_cmp+v_cndmask sgpr (2)", "v_cmp+2 v_cndmask (3)", "v_mov_b32", "v_cndmask_b32 e32 swapped", "v_bfi_b32"};
+    double ms[50];
 #define RUN(i) ms[i] = run<i>(d_out, blocks);
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20)
-    RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37) RUN(38) RUN(39) RUN(40) RUN(41) RUN(42) RUN(43) RUN(44) RUN(45) RUN(46) RUN(47)
+    RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28) RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37) RUN(38) RUN(39) RUN(40) RUN(41) RUN(42) RUN(43) RUN(44) RUN(45) RUN(46) RUN(47) RUN(48) RUN(49)
     // per SIMD: (blocks * 4 waves / 1024 SIMDs) waves x ITER x 8 instructions
     const double per_simd = (double)blocks * 4 / 1024 * ITER * 8;
     const double ns_fma = ms[0] * 1e6 / per_simd;
     printf("{\"waves_per_simd\": %d, \"assumed_v_fma_f32_cycles\": 4, \"ns_per_v_fma_f32\": %.4f, \"implied_clock_GHz\": %.3f, \"cycles\": {", blocks * 4 / 1024, ns_fma, 4.0 / ns_fma);
-    for (int i = 0; i < 48; i++) printf("%s\"%s\": %.2f", i ? ", " : "", names[i], ms[i] * 1e6 / per_simd / ns_fma * 4.0);
+    for (int i = 0; i < 50; i++) printf("%s\"%s\": %.2f", i ? ", " : "", names[i], ms[i] * 1e6 / per_simd / ns_fma * 4.0);
     printf("}}\n");
     return 0;
 }
