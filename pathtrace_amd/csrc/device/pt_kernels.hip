@@ -932,7 +932,7 @@ DEVI bool world_hit_fast(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[N
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fast sweep of scenes of RECTS AND BOXES ONLY (GA = false: every BASELINE scene but the volume one), round 4.  Same
+// The fast sweep, round 4 (rect and box leaves restated; sphere and constant_medium leaves as in world_hit_fast).  Same
 // program, same preconditions and the same (t, id) as world_hit_fast above, bit for bit, with fewer and cheaper
 // instructions per leaf face -- the sweep is bound by vector-instruction issue, and of the ~78 issue cycles a face cost
 // (20 two-cycle FP32 operations, 8 four-cycle compares / selects / maxima) these go:
@@ -1030,8 +1030,9 @@ DEVI void fdiv_q2_nofix(float n0, float n1, float d, float r, float &q0, float &
     q0 = fdiv_q_nofix(n0, d, r); q1 = fdiv_q_nofix(n1, d, r);
 #endif
 }
-template <int NR>
-DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], float (&out_t)[NR], int (&out_id)[NR])
+template <int NR, bool GA>
+DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
+                            const uint32_t (&vol_dim_base)[NR], float (&out_t)[NR], int (&out_id)[NR])
 {
     const float T_MIN = 0.001f, T_MAX = FLT_MAX;   // integrator.h:193,246
     v3 inv[NR];
@@ -1144,6 +1145,75 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
         else if (kind == OP_LEAF_RECT_YZ) { if (op_ieee) { asm volatile("; rect yz ieee"); RECT_LEAF(2, x, true) } else { asm volatile("; rect yz"); RECT_LEAF(2, x, false) } }
         else if (kind == OP_LEAF_RECT_XZ) { if (op_ieee) { asm volatile("; rect xz ieee"); RECT_LEAF(1, y, true) } else { asm volatile("; rect xz"); RECT_LEAF(1, y, false) } }
         else if (kind == OP_LEAF_BOX) { if (op_ieee) { asm volatile("; box ieee"); BOX_LEAF(true) } else { asm volatile("; box fast"); BOX_LEAF(false) } }
+        // Sphere and constant_medium leaves (GA scenes): world_hit_fast's arithmetic, folded with the same rule.  Their t can be NaN
+        // (a NaN boundary hit, a / a with a = |Bl|^2 outside the precondition): the tracker follows every accepted t.
+#define FOLD_GA(r, e_, t_, id_)                                                                                          \
+        {                                                                                                                \
+            float eg_ = fmaxf((e_), (t_) - cur_t[r]);                                                                    \
+            if (!kFlat) eg_ = fmaxf(eg_, skip[r]);                                                                       \
+            const bool take_ = !(eg_ > 0.0f);                                                                            \
+            cur_t[r] = take_ ? (t_) : cur_t[r];                                                                          \
+            cur_id[r] = take_ ? (id_) : cur_id[r];                                                                       \
+            chk = __builtin_fmaf(0.0f, cur_t[r], chk);                                                                   \
+        }
+        else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float t1v, t2v;
+                int f1, f2;
+                if (op_ieee) {
+                    asm volatile("; volbox ieee");
+                    box_hit_shared(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_shared(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                } else {
+                    asm volatile("; volbox fast");
+                    box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
+                    box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                }
+                bool hit = (f1 >= 0) && (f2 >= 0);
+                chk = __builtin_fmaf(0.0f, t1v, chk);   // a NaN boundary t: let the general sweep decide
+                chk = __builtin_fmaf(0.0f, t2v, chk);
+                t1v = (t1v < T_MIN) ? T_MIN : t1v;
+                t2v = (t2v > T_MAX) ? T_MAX : t2v;
+                hit = hit && !(t1v >= t2v);
+                t1v = (t1v < 0) ? 0.0f : t1v;
+                const float dlen = vlen(Bl[r]);
+                const float distance_inside = (t2v - t1v) * dlen;
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
+                const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
+                hit = hit && (hit_distance < distance_inside);
+                const float tv = t1v + hit_distance / dlen;
+                FOLD_GA(r, hit ? 0.0f : 1.0f, tv, op_id_base)
+            }
+        } else if (GA && kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95 (IEEE divisions: a = |Bl|^2 may leave the precondition)
+            const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+            const float c = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const float a = vdot(Bl[r], Bl[r]);
+                const float b = vdot(oc, Bl[r]);
+                const float disc = b * b - a * c;
+                const float ta = (-b - sqrtf(disc)) / a, tb = (-b + sqrtf(disc)) / a;
+                const bool ha = (ta < T_MAX) && (ta > T_MIN), hb = (tb < T_MAX) && (tb > T_MIN);
+                const float ts = ha ? ta : tb;
+                FOLD_GA(r, ((disc > 0) && (ha || hb)) ? 0.0f : 1.0f, ts, op_id_base)
+            }
+        } else if (GA && kind == OP_LEAF_VOLSPHERE) {   // constant_medium::hit volume.h:29-93 with a sphere boundary
+            const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+            const float c = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                float t1v = 0.0f, t2v = 0.0f, tv;
+                bool hit = sphere_t(oc, c, Bl[r], -FLT_MAX, FLT_MAX, t1v);
+                hit = hit && sphere_t(oc, c, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v);
+                chk = __builtin_fmaf(0.0f, t1v, chk);
+                chk = __builtin_fmaf(0.0f, t2v, chk);
+                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
+                hit = medium_decide(hit, t1v, t2v, Bl[r], OPF(18), u, tv);
+                FOLD_GA(r, hit ? 0.0f : 1.0f, tv, op_id_base)
+            }
+        }
+#undef FOLD_GA
         // OP_LEAF_NONE: never a hit
 #undef BOX_LEAF
 #undef BOX_AXIS
@@ -1293,9 +1363,9 @@ DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], u
             general = __any(redo && lane_valid);
         } else
         {
-            // scenes of rects and boxes only take the round-4 form of the fast sweep (PT_FAST_RB=0: the A/B)
+            // the round-4 form of the fast sweep (PT_FAST_RB=0: world_hit_fast, the A/B)
             bool redo;
-            if constexpr (!GA && PT_FAST_RB) redo = world_hit_fast_rb<NR>(S, lane_valid, A, B, out_t, out_id);
+            if constexpr (PT_FAST_RB) redo = world_hit_fast_rb<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
             else redo = world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
             general = __any(redo && lane_valid);
         }

@@ -231,7 +231,11 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     // register budget is spilled the moment it arrives
     const char *waves = "-DPT_CONNECT_WAVES=5";
     if (env.waves == "4") waves = "-DPT_CONNECT_WAVES=4"; else if (env.waves == "6") waves = "-DPT_CONNECT_WAVES=6";
-    q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    // -pragma-unroll-threshold: the sweep's op loop must unroll COMPLETELY for the table to fold into the code (kind, shapes and
+    // constants are only compile-time values per unrolled iteration).  LLVM sizes the unrolled loop before it folds the per-kind
+    // dispatch away -- every body of every leaf kind times PT_SPEC_N -- and past 16384 it quietly keeps a run-time loop that
+    // fetches the table from constant memory and carries all bodies (seen on the volume scene: k_connect 18.7 against 16.2 ms).
+    q.opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=4000000"};
     if (env.generic.empty()) { q.opts.push_back(waves); q.opts.push_back(env.pf == "1" ? "-DPT_CONNECT_PREFETCH=1" : (env.pf == "2" ? "-DPT_CONNECT_PREFETCH=2" : "-DPT_CONNECT_PREFETCH=0")); }
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
     const std::string &extra = env.flags;   // measurement: more compiler options, space separated

@@ -99,3 +99,23 @@ def test_provenance_names_the_compiler_and_survives_a_hostile_environment(monkey
     info = pt.spec_build_info(sc, 4)
     assert info["built_by"] == "in-process" and "is not there" in info.get("note", ""), info
     assert info["own_compiler"] in (True, False) and info["producer"]
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume", "three_orbs", "textured_room"])
+def test_the_table_folds_into_the_code(scene, tmp_path, monkeypatch):
+    # The point of the per-scene build: the op loop unrolls completely and the table becomes literals.  LLVM sizes the unrolled
+    # loop BEFORE it folds the per-kind dispatch and, past a threshold, quietly keeps a run-time loop over a table in constant
+    # memory that carries every leaf body (round 4: the volume scene's k_connect, 18.7 against 16.2 ms).  No instruction of the
+    # module may refer to the table.
+    import os
+    import subprocess
+    from pathtrace_amd import build as ptb
+
+    out = tmp_path / "m.co"
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_DUMP", str(out))
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_FOLD=1")   # a key nothing has cached: this build runs now
+    sc = pt.Scene(scene_path(scene), 64, 36)
+    assert pt.spec_build_check(sc, 4) > 20000
+    objdump = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(ptb.HIPCC))), "lib", "llvm", "bin", "llvm-objdump")
+    text = subprocess.run([objdump, "-d", str(out)], capture_output=True, text=True).stdout
+    assert "k_connect" in text and "k_extend" in text and "kSpecW" not in text
