@@ -81,11 +81,14 @@ namespace ptd {
 #ifndef PT_LIGHT_UNROLL
 #define PT_LIGHT_UNROLL 1    // k_shade's light-sample loop of the one-rect-light case: samples in flight per iteration (measurement knob)
 #endif
-#define PT_LIGHT_ONE(P, k_) rect_light_sample(PlaneTag<P>{}, (k_), base + NV + (k_) * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y)
+#define PT_LIGHT_ONE(P, F, k_) rect_light_sample(PlaneTag<P>{}, BoolTag<F>{}, (k_), base + NV + (k_) * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y)
 #if PT_LIGHT_UNROLL == 2   // two samples per iteration (independent chains side by side), a last one for odd counts
-#define PT_LIGHT_LOOP(P) { uint32_t k = 0; for (; k + 1 < L; k += 2) { PT_LIGHT_ONE(P, k); PT_LIGHT_ONE(P, k + 1); } if (k < L) PT_LIGHT_ONE(P, k); }
+#define PT_LIGHT_LOOP(P, F) { uint32_t k = 0; for (; k + 1 < L; k += 2) { PT_LIGHT_ONE(P, F, k); PT_LIGHT_ONE(P, F, k + 1); } if (k < L) PT_LIGHT_ONE(P, F, k); }
 #else
-#define PT_LIGHT_LOOP(P) for (uint32_t k = 0; k < L; k++) PT_LIGHT_ONE(P, k);
+#define PT_LIGHT_LOOP(P, F) for (uint32_t k = 0; k < L; k++) PT_LIGHT_ONE(P, F, k);
+#endif
+#ifndef PT_SHADE_FDIV
+#define PT_SHADE_FDIV 1      // k_shade's rect-light sample loop divides on pt_fdiv.h's form behind range checks (0: IEEE sequences, the A/B)
 #endif
 #ifndef PT_PK_DIV
 #define PT_PK_DIV 1          // world_hit_fast_rb: the two sides of a box axis divide on packed FP32 (0: one quotient at a time)
@@ -1030,6 +1033,36 @@ DEVI void fdiv_q2_nofix(float n0, float n1, float d, float r, float &q0, float &
     q0 = fdiv_q_nofix(n0, d, r); q1 = fdiv_q_nofix(n1, d, r);
 #endif
 }
+// Exact divisions of k_shade's light-sample loop without the IEEE scaffolding (PT_SHADE_FDIV).  hipcc expands every n / d into
+// v_div_scale x2, v_rcp, four fma, a mul, v_div_fmas, v_div_fixup (~47 issue cycles) and shares NOTHING between quotients over
+// one denominator (v_div_scale looks at both operands) -- nine such sequences per light sample, half the sample's cycles.
+// pt_fdiv.h's division (refined reciprocal shared by the numerators of one denominator, two residual corrections, v_div_fixup
+// for zero / infinite / NaN operands) returns the same correctly rounded quotient whenever no intermediate leaves the normal
+// range; two quotients over one denominator run on packed FP32.  The loop therefore runs on it and CHECKS the ranges that
+// make it exact as it goes (gmin / gmax in k_shade, per lane); a wave in which any lane left them repeats the loop with the
+// IEEE divisions.
+DEVI void fdiv_q2(float n0, float n1, float d, float r, float &q0, float &q1)
+{   // two fdiv_q (pt_fdiv.h) over one denominator, statement for statement per component
+    pt_pk2 n; n.x = n0; n.y = n1;
+    pt_pk2 dd; dd.x = d; dd.y = d;
+    pt_pk2 rr; rr.x = r; rr.y = r;
+    pt_pk2 q = n * rr;
+    pt_pk2 rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    q0 = __builtin_amdgcn_div_fixupf(q.x, d, n0);
+    q1 = __builtin_amdgcn_div_fixupf(q.y, d, n1);
+}
+DEVI v3 vdivf_fast(v3 v, float d)
+{
+    const float r = fdiv_rcp(d);
+    v3 o;
+    fdiv_q2(v.x, v.y, d, r, o.x, o.y);
+    o.z = fdiv_q(v.z, d, r);
+    return o;
+}
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int NR, bool GA>
 DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                             const uint32_t (&vol_dim_base)[NR], float (&out_t)[NR], int (&out_id)[NR])
@@ -2239,12 +2272,32 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             const v3 ab = vmul(att, beta);
             // the tail every sample shares: MIS weight, attenuation * beta * weight_l / light_pdf_l * dropoff
             // (* light_emission / pick_pdf in connect), the record
-            auto emit_sample = [&](const uint32_t k, v3 ldir, float cos_l, float light_pdf_l) {
+            // fast_c (BoolTag): the divisions run on pt_fdiv.h's form and gmin / gmax collect what would make that inexact.  Ranges
+            // (zero, and for light_pdf_l / weight_l a non-finite value, are handled by v_div_fixup and allowed where noted):
+            //   light_pdf_l within [2^-45, 2^20]  =>  fp = light_pdf_l^2 within [2^-90, 2^40]: a numerator >= 2^-101, fp + g^2 (g <= 1 / pi)
+            //   within [2^-90, 2^41], weight_l = fp / (fp + g^2) >= 2^-87;
+            //   weight_l within [2^-40, 1] and the components of ab within [2^-60, 2^30] (once per hit; throughput decays with every
+            //   coloured bounce, so the lower limit is generous)  =>  weight_l * ab >= 2^-100 and its quotient by light_pdf_l within
+            //   [2^-120, 2^75].
+            // The checks cost no branch and no scalar instruction: every checked magnitude, scaled so that its lower limit is 1,
+            // feeds a running minimum (gmin), scaled so that its upper limit is 1 a running maximum (gmax); the loop was exact iff
+            // gmin >= 1 and gmax <= 1 at its end.  Zeros trip the minimum (rare: a wave then takes the IEEE loop); NaNs and
+            // infinities pass through both (ignored by min / max) and need no check: v_div_fixup gives non-finite operands the
+            // IEEE result.
+            float gmin = 1.0f, gmax = 1.0f;
+            auto emit_sample = [&](auto fast_c, const uint32_t k, v3 ldir, float cos_l, float light_pdf_l) {
+                constexpr bool FAST = decltype(fast_c)::value;
                 const float scatter_pdf_l = material_value_of(mat_type, cos_l);   // cosine_pdf's cosine IS cos_l (pdf.h:20)
-                const float weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
+                float weight_l;
+                if (FAST) {   // power_heuristic helpers.h:138-144 with the division restated
+                    const float fp = light_pdf_l * light_pdf_l;
+                    weight_l = fdiv(fp, fp + scatter_pdf_l * scatter_pdf_l);
+                    gmin = fminf(gmin, fminf(fabsf(light_pdf_l) * 0x1p45f, weight_l * 0x1p40f));
+                    gmax = fmaxf(gmax, fmaxf(fabsf(light_pdf_l) * 0x1p-20f, weight_l));
+                } else weight_l = power_heuristic(light_pdf_l, scatter_pdf_l);
                 const float dropoff = cos_l > 0.0f ? cos_l : 0.0f;
                 v3 c = vscale(weight_l, ab);
-                c = vdivf(c, light_pdf_l);
+                c = FAST ? vdivf_fast(c, light_pdf_l) : vdivf(c, light_pdf_l);
                 c = vscale(dropoff, c);
                 if (!att_ok) c = V(NAN, NAN, NAN);   // contribution skipped: NaN is dropped by connect like integrator.h:255
                 if (stage) {
@@ -2265,8 +2318,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             // The rect's fields may be per-lane values (the light a lane drew) or wave-uniform; the alignment is wave-uniform and
             // a compile-time constant here (plane_c: std::integral_constant-like tag): as a run-time value its shuffles were
             // eight scalar branches with register moves per sample.
-            auto rect_light_sample = [&](auto plane_c, const uint32_t k, const uint32_t kb, v3 tl, float x0, float z0, float x1, float z1, float y) {
+            // fast_c: see emit_sample.  Its own ranges: every component of ldir within [2^-20, 2^20] (not zero) => |ldir| within
+            // [2^-20, 2^22], the four quotients by it within [2^-42, 2^40]; d2 = |ldir|^2 >= 2^-40, cosine * area within [2^-62, 2^40]
+            // for an area within [2^-20, 2^40], light_pdf_l within [2^-80, 2^105] (and checked against [2^-45, 2^20] afterwards).
+            auto rect_light_sample = [&](auto plane_c, auto fast_c, const uint32_t k, const uint32_t kb, v3 tl, float x0, float z0, float x1, float z1, float y) {
                 constexpr int plane = decltype(plane_c)::value;
+                constexpr bool FAST = decltype(fast_c)::value;
                 const v3 ol = V(tl.x + hp.x, tl.y + hp.y, tl.z + hp.z);
                 const v3 os = shuffle(ol, plane);
                 const float area = (x1 - x0) * (z1 - z0);
@@ -2276,17 +2333,31 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const float px = (float)((double)x0 + rx * (double)(x1 - x0));
                 const v3 ldir = vsub(shuffle(V(px, y, pz), plane), ol);
                 const float vl = vlen(ldir);
-                const float cos_l = vdot(vdivf(ldir, vl), hnu);
                 const v3 ds = shuffle(ldir, plane);
+                float cos_l, cosine_f = 0.0f;
+                if (FAST) {   // unit_vector(ldir) and |ds.y| / |ldir|: four quotients over one denominator, two packed pairs
+                    const float rv = fdiv_rcp(vl);
+                    v3 u;
+                    fdiv_q2(ldir.x, ldir.y, vl, rv, u.x, u.y);
+                    fdiv_q2(ldir.z, fabsf(ds.y), vl, rv, u.z, cosine_f);
+                    cos_l = vdot(u, hnu);
+                    // A hit ON the light's plane (every emitter hit: 3 % of the hits, some lane of most waves) has ds.y == 0 exactly:
+                    // tq is NaN then and so is every coefficient whatever the quotients are (0 / |ldir| is exact anyway), so a
+                    // zero plane component does not count against the lower limit
+                    const float py = (ds.y == 0.0f) ? 1.0f : fabsf(ds.y);
+                    const float lo = fminf(fminf(fabsf(ds.x), py), fabsf(ds.z)), hi = fmaxf(fmaxf(fabsf(ldir.x), fabsf(ldir.y)), fabsf(ldir.z));
+                    gmin = fminf(gmin, lo * 0x1p20f);
+                    gmax = fmaxf(gmax, hi * 0x1p-20f);
+                } else cos_l = vdot(vdivf(ldir, vl), hnu);
                 const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
                 const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
                 float light_pdf_l = 0.0f;
                 if (!(xh < x0 || xh > x1 || zh < z0 || zh > z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
                     const float d2 = (tq * vl) * (tq * vl);
-                    const float cosine = fabsf(ds.y) / vl;
-                    light_pdf_l = d2 / (cosine * area);
+                    const float cosine = FAST ? cosine_f : fabsf(ds.y) / vl;
+                    light_pdf_l = FAST ? fdiv(d2, cosine * area) : d2 / (cosine * area);
                 }
-                emit_sample(k, ldir, cos_l, light_pdf_l);
+                emit_sample(fast_c, k, ldir, cos_l, light_pdf_l);
             };
             // one light (the common case): its index is wave-uniform, so its instance/primitive records are scalar
             // loads and the pick draw (always index 0) is not needed; several lights: per-lane gather.
@@ -2298,7 +2369,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const v3 ldir = tr ? dl : xf_linear(lin.fwd, dl);
                 const float cos_l = vdot(vunit(ldir), hnu);
                 const float light_pdf_l = prim_pdf_value(lpr, ol, tr ? ldir : xf_linear(lin.inv, ldir));   // primitive.h:319-337
-                emit_sample(k, ldir, cos_l, light_pdf_l);
+                emit_sample(BoolTag<false>{}, k, ldir, cos_l, light_pdf_l);
             };
             if (LM == 1) {
                 const DInst &lin = S.insts[S.lights[0]];
@@ -2308,9 +2379,31 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     const DRect &lq = lpr.r[0];
                     const v3 tl = V(lin.inv[3], lin.inv[7], lin.inv[11]);
                     // one loop per alignment (wave-uniform branch); the empty asm keeps the three bodies apart
-                    if (lq.plane == 0) { asm volatile("; rect light xy"); PT_LIGHT_LOOP(0) }
-                    else if (lq.plane == 2) { asm volatile("; rect light yz"); PT_LIGHT_LOOP(2) }
-                    else { asm volatile("; rect light xz"); PT_LIGHT_LOOP(1) }
+                    // the loop on the cheap divisions first; a wave in which a lane left their ranges repeats it on the IEEE ones
+                    bool redo = true;
+                    const float area = (lq.x1 - lq.x0) * (lq.z1 - lq.z0);   // wave-uniform
+                    if (PT_SHADE_FDIV && fdiv_in_range_nz(area, -20, 40)) {
+                        gmin = fminf(fminf(ab.x, ab.y), ab.z) * 0x1p60f;   // attenuation * beta: non-negative components
+                        gmax = fmaxf(fmaxf(ab.x, ab.y), ab.z) * 0x1p-30f;
+                        gmax = fmaxf(gmax, 1.0f); gmin = fminf(gmin, 1.0f);
+                        if (lq.plane == 0) { asm volatile("; rect light xy fast"); PT_LIGHT_LOOP(0, true) }
+                        else if (lq.plane == 2) { asm volatile("; rect light yz fast"); PT_LIGHT_LOOP(2, true) }
+                        else { asm volatile("; rect light xz fast"); PT_LIGHT_LOOP(1, true) }
+                        // a lane whose attenuation test failed stores NaN coefficients whatever the loop computed (att_ok)
+                        redo = __any(att_ok && (!(gmin >= 1.0f) || !(gmax <= 1.0f)));
+#ifdef PT_DBG_FDIV_NOREDO   // timing-only build: never repeat (images may differ)
+                        redo = false;
+#endif
+#ifdef PT_DBG_FDIV_COUNT    // debugging: how often a wave repeats the loop (counted into term_pdf's word: wrong counters on purpose)
+                        if (redo && lane == 0) n_pdf += 1;
+#endif
+                        if (redo) lit = !stage;
+                    }
+                    if (redo) {
+                        if (lq.plane == 0) { asm volatile("; rect light xy"); PT_LIGHT_LOOP(0, false) }
+                        else if (lq.plane == 2) { asm volatile("; rect light yz"); PT_LIGHT_LOOP(2, false) }
+                        else { asm volatile("; rect light xz"); PT_LIGHT_LOOP(1, false) }
+                    }
                 } else {
                     for (uint32_t k = 0; k < L; k++) light_sample(k, base + NV + k * (3u + NV), lin, lpr, tr);
                 }
@@ -2322,19 +2415,35 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 // both rects of one alignment under pure translations (cornell_box_small_lights): the shortcut above with the
                 // drawn light's eight fields selected per lane
                 const bool both_tr = ia.ident && ib.ident && wave_finite && pa.type == 0 && pb.type == 0 && pa.r[0].plane == pb.r[0].plane;
+                if (both_tr) {
+                    const DRect &qa = pa.r[0], &qb = pb.r[0];
+                    // the drawn light's fields per lane, then the one-light loop's body; on the cheap divisions first (see LM == 1)
+                    auto both_loop = [&](auto fast_c) {
+                        for (uint32_t k = 0; k < L; k++) {
+                            const uint32_t kb = base + NV + k * (3u + NV);
+                            const bool second = (int)(rnd(k0, k1, kb + 0) * 2.0) != 0;            // world.h:31-35
+                            const v3 tl = V(second ? ib.inv[3] : ia.inv[3], second ? ib.inv[7] : ia.inv[7], second ? ib.inv[11] : ia.inv[11]);
+                            const float x0 = second ? qb.x0 : qa.x0, z0 = second ? qb.z0 : qa.z0, x1 = second ? qb.x1 : qa.x1, z1 = second ? qb.z1 : qa.z1;
+                            const float y = second ? qb.y : qa.y;
+                            if (qa.plane == 0) { asm volatile("; rect lights xy"); rect_light_sample(PlaneTag<0>{}, fast_c, k, kb, tl, x0, z0, x1, z1, y); }
+                            else if (qa.plane == 2) { asm volatile("; rect lights yz"); rect_light_sample(PlaneTag<2>{}, fast_c, k, kb, tl, x0, z0, x1, z1, y); }
+                            else { asm volatile("; rect lights xz"); rect_light_sample(PlaneTag<1>{}, fast_c, k, kb, tl, x0, z0, x1, z1, y); }
+                        }
+                    };
+                    const float area_a = (qa.x1 - qa.x0) * (qa.z1 - qa.z0), area_b = (qb.x1 - qb.x0) * (qb.z1 - qb.z0);   // wave-uniform
+                    bool redo = true;
+                    if (PT_SHADE_FDIV && fdiv_in_range_nz(area_a, -20, 40) && fdiv_in_range_nz(area_b, -20, 40)) {
+                        gmin = fminf(fminf(fminf(ab.x, ab.y), ab.z) * 0x1p60f, 1.0f);
+                        gmax = fmaxf(fmaxf(fmaxf(ab.x, ab.y), ab.z) * 0x1p-30f, 1.0f);
+                        both_loop(BoolTag<true>{});
+                        redo = __any(att_ok && (!(gmin >= 1.0f) || !(gmax <= 1.0f)));
+                        if (redo) lit = !stage;
+                    }
+                    if (redo) both_loop(BoolTag<false>{});
+                } else
                 for (uint32_t k = 0; k < L; k++) {
                     const uint32_t kb = base + NV + k * (3u + NV);
                     const bool second = (int)(rnd(k0, k1, kb + 0) * 2.0) != 0;            // world.h:31-35
-                    if (both_tr) {
-                        const DRect &qa = pa.r[0], &qb = pb.r[0];
-                        const v3 tl = V(second ? ib.inv[3] : ia.inv[3], second ? ib.inv[7] : ia.inv[7], second ? ib.inv[11] : ia.inv[11]);
-                        const float x0 = second ? qb.x0 : qa.x0, z0 = second ? qb.z0 : qa.z0, x1 = second ? qb.x1 : qa.x1, z1 = second ? qb.z1 : qa.z1;
-                        const float y = second ? qb.y : qa.y;
-                        if (qa.plane == 0) { asm volatile("; rect lights xy"); rect_light_sample(PlaneTag<0>{}, k, kb, tl, x0, z0, x1, z1, y); }
-                        else if (qa.plane == 2) { asm volatile("; rect lights yz"); rect_light_sample(PlaneTag<2>{}, k, kb, tl, x0, z0, x1, z1, y); }
-                        else { asm volatile("; rect lights xz"); rect_light_sample(PlaneTag<1>{}, k, kb, tl, x0, z0, x1, z1, y); }
-                        continue;
-                    }
                     DInst lin;
                     DPrim lpr;
 #pragma unroll
