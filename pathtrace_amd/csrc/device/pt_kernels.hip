@@ -87,6 +87,9 @@ namespace ptd {
 #else
 #define PT_LIGHT_LOOP(P, F) for (uint32_t k = 0; k < L; k++) PT_LIGHT_ONE(P, F, k);
 #endif
+#ifndef PT_SHADE_TRIM
+#define PT_SHADE_TRIM 1      // k_shade's light-sample loop: branch-free in-bounds select and "can contribute" test (0: the A/B)
+#endif
 #ifndef PT_SHADE_FDIV
 #define PT_SHADE_FDIV 1      // k_shade's rect-light sample loop divides on pt_fdiv.h's form behind range checks (0: IEEE sequences, the A/B)
 #endif
@@ -2285,6 +2288,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             // infinities pass through both (ignored by min / max) and need no check: v_div_fixup gives non-finite operands the
             // IEEE result.
             float gmin = 1.0f, gmax = 1.0f;
+            float litacc = 0.0f;   // PT_SHADE_TRIM: largest |c|_1 over the samples staged so far
             auto emit_sample = [&](auto fast_c, const uint32_t k, v3 ldir, float cos_l, float light_pdf_l) {
                 constexpr bool FAST = decltype(fast_c)::value;
                 const float scatter_pdf_l = material_value_of(mat_type, cos_l);   // cosine_pdf's cosine IS cos_l (pdf.h:20)
@@ -2303,7 +2307,13 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 if (stage) {
                     st_d[k * PT_BLOCK] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                     st_e[k * PT_BLOCK] = make_float2(c.y, c.z);
+#if PT_SHADE_TRIM
+                    // "no component NaN and some component non-zero" <=> |c.x| + |c.y| + |c.z| > 0 (the sum is NaN iff a component is;
+                    // +inf counts as non-zero): the running maximum ignores NaN sums and is positive iff some sample can contribute
+                    litacc = fmaxf(litacc, fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
+#else
                     lit = lit || (!v_is_nan(c) && (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f));
+#endif
                 } else {
                     sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                     sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
@@ -2352,6 +2362,17 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
                 const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
                 float light_pdf_l = 0.0f;
+#if PT_SHADE_TRIM
+                if (FAST) {
+                    // the quotient is formed for every lane (some lane of the wave needs it anyway) and kept where the reference's
+                    // "xh < x0 || xh > x1 || zh < z0 || zh > z1" is false: one maximum decided by its sign, NaN coordinates pass
+                    // (ignored by the maximum, false in the reference's comparisons) -- no branch, no mask arithmetic
+                    const float d2 = (tq * vl) * (tq * vl);
+                    const float lp = fdiv(d2, cosine_f * area);
+                    const float eo = fmaxf(fmaxf(x0 - xh, xh - x1), fmaxf(z0 - zh, zh - z1));
+                    light_pdf_l = (eo > 0.0f) ? 0.0f : lp;
+                } else
+#endif
                 if (!(xh < x0 || xh > x1 || zh < z0 || zh > z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
                     const float d2 = (tq * vl) * (tq * vl);
                     const float cosine = FAST ? cosine_f : fabsf(ds.y) / vl;
@@ -2397,7 +2418,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
 #ifdef PT_DBG_FDIV_COUNT    // debugging: how often a wave repeats the loop (counted into term_pdf's word: wrong counters on purpose)
                         if (redo && lane == 0) n_pdf += 1;
 #endif
-                        if (redo) lit = !stage;
+                        if (redo) { lit = !stage; litacc = 0.0f; }
                     }
                     if (redo) {
                         if (lq.plane == 0) { asm volatile("; rect light xy"); PT_LIGHT_LOOP(0, false) }
@@ -2437,7 +2458,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                         gmax = fmaxf(fmaxf(fmaxf(ab.x, ab.y), ab.z) * 0x1p-30f, 1.0f);
                         both_loop(BoolTag<true>{});
                         redo = __any(att_ok && (!(gmin >= 1.0f) || !(gmax <= 1.0f)));
-                        if (redo) lit = !stage;
+                        if (redo) { lit = !stage; litacc = 0.0f; }
                     }
                     if (redo) both_loop(BoolTag<false>{});
                 } else
@@ -2465,6 +2486,9 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     light_sample(k, kb, lin, S.prims[lin.prim], false);
                 }
             }
+#if PT_SHADE_TRIM
+            if (stage) lit = litacc > 0.0f;
+#endif
         }
         if (stage) {
             o = reserve(shadow && lit, &sq.count[seg_o], 1);

@@ -91,7 +91,7 @@ def _exchange_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_owned_tile_exchange_assembles_the_frame(tmp_path, world):
     # bench.py's N > 1 exchange: every rank sends only the pixels of its tiles (one gather of 1/N-frame buffers), rank 0
     # writes them in place -- the assembled frame holds every pixel's owner's value and nothing else

@@ -52,6 +52,24 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank():
     assert two["scaling_proxy"] is None
 
 
+def test_bench_four_rank_rehearsal_of_the_launch_path():
+    # The launch path of the multi-GPU bench with as many ranks as one GPU box safely lets share its card (its process guard
+    # allows six processes on the GPU, this test runner is one of them; eight ranks are the driver's to run on eight GPUs; the
+    # eight-way ownership map and exchange are covered on the CPU, tests/test_distributed_gloo.py): bench.py starts torch.distributed.run itself, every rank runs the one-pass planner, derives
+    # the same ownership map, waits for its own per-scene build, renders its tiles and the owned-tile gather assembles the frame
+    # on rank 0 -- rays, samples and the framebuffer checksum equal N = 1.
+    common = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-scaling-proxy"]
+    small = {"PT_BENCH_SIZE": "640x360"}
+    one = run_bench(["--gpus", "1"] + common, small)
+    four = run_bench(["--gpus", "4"] + common, dict(small, PT_BENCH_REHEARSAL="1"))
+    assert four["n_gpus"] == 4 and four["scaling"] == "strong" and "gather of owned tiles" in four["config"]["exchange"]
+    for k in ("spp_total", "camera_samples", "rays", "rays_traced", "framebuffer_sum"):
+        assert one["config"][k] == four["config"][k], (k, one["config"][k], four["config"][k])
+    # the exchange moved the other ranks' tiles (rank 0's own stay): less than one frame, not three frames
+    moved = int(four["config"]["exchange"].split(":")[1].split()[0])
+    assert 0 < moved < 640 * 360 * 16
+
+
 def test_rccl_world_size_one_reduce_of_the_library_framebuffer():
     code = r"""
 import os, sys, numpy as np

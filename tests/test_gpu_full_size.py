@@ -22,11 +22,21 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+@pytest.fixture(params=["off", "sync"], ids=["generic", "module"])
+def spec(request, monkeypatch):
+    # the library's generic kernels, and the per-scene module (hiprtc at pt_create) that production runs and bench.py times
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("scene,w,h", CASES)
-def test_full_frame_windows_counters_and_tile_partition(oracle, scene, w, h):
+def test_full_frame_windows_counters_and_tile_partition(oracle, scene, w, h, spec):
     spp, L = 2, 4
     sc = pt.Scene(scene_path(scene), w, h)
     r = pt.Renderer(sc)                       # default batch size: the frame is cut into bands
+    assert (r.spec_status() == 1) == (spec == "sync"), pt.last_error()
+    if spec == "sync":
+        assert r.spec_info()["own_compiler"] is True, r.spec_info()
     whole = r.render(spp)
     c = r.counters()
     # conservation: one termination per camera sample, light_samples shadow rays per hit, rays = extension + shadow
@@ -64,7 +74,7 @@ FULL = [("cornell_box_small_lights", 1920, 1080, 4096, 16, 8.05), ("cornell_box_
 
 
 @pytest.mark.parametrize("scene,w,h,spp,batch,rays_per_sample", FULL)
-def test_full_sample_count_of_baseline_configs(oracle, scene, w, h, spp, batch, rays_per_sample):
+def test_full_sample_count_of_baseline_configs(oracle, scene, w, h, spp, batch, rays_per_sample, spec):
     """The whole configuration (every sample of every pixel) through the wavefront path, 33 M paths per batch: counter
     conservation at 10^10..10^11 camera samples, the survey's ray mix, and -- at full spp -- the framebuffer SUM of an
     8x8 window equal to the oracle's bit for bit (the oracle renders the same (pixel, sample) streams in sample order).
@@ -72,6 +82,7 @@ def test_full_sample_count_of_baseline_configs(oracle, scene, w, h, spp, batch, 
     L = 4
     sc = pt.Scene(scene_path(scene), w, h)
     r = pt.Renderer(sc, max_paths_in_flight=w * h * batch)
+    assert (r.spec_status() == 1) == (spec == "sync"), pt.last_error()
     for s in range(0, spp, batch):
         r.render_async(s, s + batch)
     fb = r.framebuffer()
