@@ -2363,7 +2363,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
                 float light_pdf_l = 0.0f;
 #if PT_SHADE_TRIM
-                if (FAST) {
+                if (FAST && !B0) {   // (the bounce-0 instantiation has no register to spare for it: 18 spilled VGPRs)
                     // the quotient is formed for every lane (some lane of the wave needs it anyway) and kept where the reference's
                     // "xh < x0 || xh > x1 || zh < z0 || zh > z1" is false: one maximum decided by its sign, NaN coordinates pass
                     // (ignored by the maximum, false in the reference's comparisons) -- no branch, no mask arithmetic

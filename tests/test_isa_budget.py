@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-VALU = ("fp2", "fp2s", "v4", "pk", "trans")
+VALU = ("fp2", "fp2s", "fma", "v4", "pk", "f64", "trans")
 # kernel -> (min occupancy, max static VALU instructions, max basic block, max scalar instructions, max spilled VGPRs,
 #            max spilled SGPRs: a spilled SGPR is a v_writelane / v_readlane pair through a VGPR the kernel then cannot use)
 BUDGET = {

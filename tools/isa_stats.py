@@ -5,10 +5,14 @@
 
 Compiles pathtrace_amd/csrc/device/pt_kernels.hip to assembly with the product's flags and prints, per kernel:
 registers, spills, occupancy, and the instruction mix split by the issue classes measured on MI355X:
-  fp2   v_mul/add/sub/fma_f32 whose operands are VGPRs / constants only  (2 cycles per wave64 instruction)
-  fp2s  the same with an SGPR operand                                     (4 cycles)
-  v4    every other VALU instruction (compare, select, min/max, integer, convert, div scaffolding)  (4 cycles)
-  trans v_rcp/rsq/sqrt/exp/log/sin/cos_f32, f64 arithmetic                (8+ cycles)
+  fp2   v_mul/add/sub_f32 whose operands are VGPRs / constants only       (2.3 - 2.6 cycles per wave64 instruction)
+  fp2s  the same with an SGPR operand                                     (3.9)
+  fma   v_fma / v_fmac / v_mac / v_mad_f32 (three register reads)         (3.8 - 4.0; round 4's microbench: it is NOT a 2-cycle class)
+  v4    every other 32-bit VALU instruction (compare, select, min/max, integer, convert, div scaffolding)  (4)
+  pk    v_pk_*_f32: two results per lane                                  (4.1)
+  f64   f64 arithmetic and conversions                                    (4.0 - 4.5)
+  trans v_rcp/rsq/sqrt/exp/log/sin/cos_f32                                (7.8), v_rcp_f64 16
+(tools/microbench/valu_rates.hip; ISSUE_CYCLES below are the figures bench.py's issue model uses)
 --blocks lists the basic blocks of the selected kernels with their mixes (the traversal sweep's per-op bodies).
 """
 import argparse
@@ -21,16 +25,22 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-FP2 = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_fma_f32", "v_mac_f32", "v_fmac_f32", "v_mad_f32",
-       "v_mul_legacy_f32", "v_fmaak_f32", "v_fmamk_f32"}
+FP2 = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_legacy_f32"}
+FMA = {"v_fma_f32", "v_mac_f32", "v_fmac_f32", "v_mad_f32", "v_fmaak_f32", "v_fmamk_f32", "v_madak_f32", "v_madmk_f32"}
+ISSUE_CYCLES = {"fp2": 2.45, "fp2s": 3.9, "fma": 3.9, "v4": 4.0, "pk": 4.1, "f64": 4.3, "trans": 7.8}
+VALU_CLASSES = ("fp2", "fp2s", "fma", "v4", "pk", "f64", "trans")
 TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")
 
 
 def classify(op, args):
     if op.startswith("v_"):
         base = re.sub(r"_e32$|_e64$|_dpp$|_sdwa$", "", op)
-        if base.startswith(TRANS) or base.endswith("_f64") or "_f64_" in base:
+        if base.startswith(TRANS):
             return "trans"
+        if base.endswith("_f64") or "_f64_" in base:
+            return "f64"
+        if base in FMA:
+            return "fma"
         if base in FP2:
             # an SGPR source operand (s12, s[4:5], vcc, ...) puts the instruction in the 4-cycle class
             srcs = args.split(",")[1:]
@@ -51,7 +61,13 @@ def classify(op, args):
     return "other"
 
 
-KEYS = ("fp2", "fp2s", "v4", "pk", "trans", "salu", "smem", "vmem", "lds", "div*")
+KEYS = ("fp2", "fp2s", "fma", "v4", "pk", "f64", "trans", "salu", "smem", "vmem", "lds", "div*")
+
+
+def issue_cycles(total):
+    """(vector instructions, class-weighted issue cycles per vector instruction) of a static mix {class: n}."""
+    n = sum(total.get(c, 0) for c in VALU_CLASSES)
+    return n, (sum(total.get(c, 0) * ISSUE_CYCLES[c] for c in VALU_CLASSES) / n if n else 0.0)
 
 
 def analyze(flags="", src=None, keep="", kernel=""):

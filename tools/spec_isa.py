@@ -51,9 +51,9 @@ def main():
     ap.add_argument("--blocks", action="store_true")
     a = ap.parse_args()
     for k in analyze(a.scene, a.light_samples, a.flags, a.keep):
-        valu = sum(k["total"].get(c, 0) for c in ("fp2", "fp2s", "v4", "pk", "trans"))
+        valu, cyc = isa_stats.issue_cycles(k["total"])
         print(f"{k['name']}\n   vgpr {k['vgpr']} sgpr {k['sgpr']} scratch {k['scratch']} occupancy {k['occupancy']} "
-              f"sgpr_spills {k['sgpr_spills']} vgpr_spills {k['vgpr_spills']} lds {k['lds']}  VALU {valu}")
+              f"sgpr_spills {k['sgpr_spills']} vgpr_spills {k['vgpr_spills']} lds {k['lds']}  VALU {valu}, {cyc:.2f} issue cycles each (static mix)")
         print("   static: " + "  ".join(f"{c} {k['total'].get(c, 0)}" for c in isa_stats.KEYS))
         if a.blocks:
             for lab, d in k["blocks"]:

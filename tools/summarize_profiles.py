@@ -160,6 +160,31 @@ def main():
     json.dump(res, open(os.path.join(out, tag + "_hbm_traffic.json"), "w"), indent=1)
     ins = insts_per_kernel(os.path.join(d, tag + "_pmc_insts"))
     if ins:
+        # What a vector instruction of each kernel costs to issue: the class-weighted mean over the STATIC mix of the instantiation
+        # that ran (tools/isa_stats.py classes and their measured cycles, tools/microbench/valu_rates.hip) -- k_shade from the
+        # library, k_extend / k_connect from the scene's per-scene module (tools/spec_isa.py compiles it with hipcc).  bench.py's
+        # issue_frac = wave instructions per second x this / (1024 SIMDs x clock).  A static mix weighs cold blocks like hot ones:
+        # an estimate, stated as such.
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import isa_stats
+            import spec_isa
+            scene_file = os.environ.get("PT_PROFILE_SCENE") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "cornell_box.json")
+            stat = {}
+            for k in isa_stats.analyze(kernel="k_shade<false, 1, true, false>"):
+                stat["shade"] = (k["name"], isa_stats.issue_cycles(k["total"]))
+            for k in spec_isa.analyze(scene_file, 4):
+                if "k_extend" in k["name"] and k["name"].rstrip(">").endswith("false"):
+                    stat["extend"] = (k["name"], isa_stats.issue_cycles(k["total"]))
+                if "k_connect" in k["name"]:
+                    stat["connect"] = (k["name"], isa_stats.issue_cycles(k["total"]))
+            for kk, (name, (n, cyc)) in stat.items():
+                if kk in ins:
+                    ins[kk]["issue_cycles_per_valu"] = round(cyc, 3)
+                    ins[kk]["issue_cycles_from"] = f"static mix of {name} ({n} vector instructions)"
+                    ins[kk]["issue_frac"] = round(ins[kk]["valu_insts_per_s"] * cyc / (1024 * 2.4e9), 4)
+        except Exception as e:   # the counters stand without it
+            ins["issue_cycles_error"] = str(e)[:200]
         ins["kernel_source_sha16"] = sha
         ins["note"] = ("rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS "
                        "SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (tools/profile_gpu.sh " + tag + "), bench.py --steps 4 "
