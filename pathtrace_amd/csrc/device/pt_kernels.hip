@@ -2337,10 +2337,12 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const v3 ol = V(tl.x + hp.x, tl.y + hp.y, tl.z + hp.z);
                 const v3 os = shuffle(ol, plane);
                 const float area = (x1 - x0) * (z1 - z0);
-                const double rz = rnd(k0, k1, kb + 1);   // rect::random primitive.h:168-175 (first draw -> z, second -> x)
-                const double rx = rnd(k0, k1, kb + 2);
-                const float pz = (float)((double)z0 + rz * (double)(z1 - z0));
-                const float px = (float)((double)x0 + rx * (double)(x1 - x0));
+                // rect::random primitive.h:168-175 (first draw -> z, second -> x): z0 + r * (z1 - z0) in double with r = u * 2^-32.
+                // The scaling by 2^-32 is exact wherever it is applied, so (u * 2^-32) * w and u * (w * 2^-32) round the same real
+                // product: the draw stays an integer and the (loop-invariant) width carries the scale -- one f64 operation less
+                const double wz = (double)(z1 - z0) * (1.0 / 4294967296.0), wx = (double)(x1 - x0) * (1.0 / 4294967296.0);
+                const float pz = (float)((double)z0 + (double)stream_u32(k0, k1, kb + 1) * wz);
+                const float px = (float)((double)x0 + (double)stream_u32(k0, k1, kb + 2) * wx);
                 const v3 ldir = vsub(shuffle(V(px, y, pz), plane), ol);
                 const float vl = vlen(ldir);
                 const v3 ds = shuffle(ldir, plane);
