@@ -18,8 +18,8 @@ rays per hit, which is what the reference and the CPU baseline perform for the s
 cornell_box, because hits none of whose light samples can contribute get no shadow rays here; its rate is reported
 beside it as `value_reference_equivalent` and is the figure to compare with `cpu_baseline`.
 
-Launch plan (`launch_plan`): a rank's K steps are cut into wavefront batches of at most 66 M paths and at least
-2 x lanes = 6 batches (a context needs three batches in flight to fill the chip), whatever N and K are.
+Launch plan (`launch_plan`): a rank's K steps are cut into as few wavefront batches as 199 M paths each allow, at least two
+(measured: the fewest batches win, down to two -- DESIGN.md 6), whatever N and K are.
 
 N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
 partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over per-tile ray counts measured
@@ -60,7 +60,10 @@ SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
 LIGHT_SAMPLES = 4              # BASELINE configs: light_samples 4 (pt.Renderer's default)
 N_LANES = 3                    # stream lanes of a context (pt_context.cpp; PATHTRACE_HIP_LANES)
-MAX_BATCH_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", str(1920 * 1080 * 32)))   # 66 M path slots x 288 B x 3 lanes = 57 GB
+# 199 M path slots x 288 B x 3 lanes = 172 GB of the 288 GB (round 3: 66 M / 57 GB).  Bigger batches, fewer launches: same box, K = 64,
+# 66 M / 133 M / 199 M slots: 39.33 / 39.69 / 39.99 Grays/s (profiles/experiments/r04_ab_runs.json).  48 601 segments of 4096 slots
+# stay below the 2^16 the permuted segment walk multiplies in 32 bits.
+MAX_BATCH_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", str(1920 * 1080 * 96)))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector ALU roof: 256 CUs x 4 SIMDs, one wave64 FP32 mul/add/fma every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
 # v_fma_f32 2 cycles per wave64 = 157.3 TFLOP/s); other vector instruction classes issue at 4 or more cycles
@@ -142,12 +145,15 @@ def stream_bytes(kernel, d, light_samples, n_launches, pixels, generate_launches
 
 
 def launch_plan(my_pixels, total_spp):
-    """Samples per pixel of one wavefront launch: as few batches as MAX_BATCH_PATHS paths each allow, and at least one per lane
-    (three in flight fill the chip).  Independent of N.  Measured with tools/plan_probe.py (profiles/r03d_launch_plans.jsonl):
-    for every N and K the fewest batches win -- a rank of N = 8 at K = 20 takes 19.2 ms in 3 batches, 20.8 in 6, 22.8 in 12 --
-    because every batch pays its thin late bounces (30 launches of a few hundred thousand paths) once."""
+    """Samples per pixel of one wavefront launch: as few EQUAL batches as MAX_BATCH_PATHS paths each allow, and at least TWO.
+    Independent of N.  Measured with tools/plan_probe.py: for every N and K the fewest batches win, because every batch pays its
+    thin late bounces (30 launches of a few hundred thousand paths) once -- round 3: N = 8, K = 20: 19.2 ms in 3 batches, 20.8 in
+    6, 22.8 in 12 (profiles/r03d_launch_plans.jsonl) -- down to two: round 4 (profiles/r04_launch_plans.jsonl, one box) a rank of
+    N = 8 at K = 20 takes 17.6 ms in 2 batches, 18.2 in 3 (round 3's "one per lane") and 18.6 in ONE, whose tail has nothing to
+    overlap with; N = 4 (3 batches) and N = 2 (6) are at their best where the cap puts them."""
     spp_cap = max(1, MAX_BATCH_PATHS // max(my_pixels, 1))
-    want = -(-total_spp // int(os.environ.get("PT_BENCH_TARGET_BATCHES", str(N_LANES))))
+    batches = max(int(os.environ.get("PT_BENCH_TARGET_BATCHES", "2")), -(-total_spp // spp_cap))
+    want = -(-total_spp // batches)   # equal batches (the last one may be a few samples short)
     if os.environ.get("PT_BENCH_GROUP"):   # measurement knob: steps per launch
         want = SPP_PER_STEP * int(os.environ["PT_BENCH_GROUP"])
     return max(1, min(spp_cap, want))
@@ -183,7 +189,7 @@ def pmc_profile(dom):
     this build of the kernels (kernel_source_sha16 recorded in the file), and under their own key."""
     import glob
     sha = kernel_source_sha16()
-    out = {"kernel_source_sha16": sha, "traffic_bytes_per_launch": None, "traffic_source": None, "valu": None,
+    out = {"kernel_source_sha16": sha, "traffic_bytes_per_launch": None, "traffic_TBps": None, "traffic_source": None, "valu": None,
            "note": "rocprofv3 --pmc passes of tools/profile_gpu.sh (serialised dispatches), not this run; null = no summary of this build"}
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # rNNx tags sort by round
     for f in reversed(tfiles):
@@ -194,6 +200,7 @@ def pmc_profile(dom):
         if d.get("kernel_source_sha16") == sha and dom in d:
             out["traffic_bytes_per_launch"] = d[dom].get("hbm_bytes_per_launch")
             out["traffic_seconds_per_launch"] = d[dom].get("seconds_per_launch")
+            out["traffic_TBps"] = d[dom].get("TBps")   # bytes and seconds of the SAME pass (its launches hold 32 spp: PT_BENCH_GROUP=2)
             out["traffic_source"] = "profiles/" + os.path.basename(f)
             break
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instruction_mix.json")))):
@@ -429,6 +436,11 @@ def main():
     r.set_profiling(False)
     r.set_lanes(N_LANES if not os.environ.get("PATHTRACE_HIP_LANES") else int(os.environ["PATHTRACE_HIP_LANES"]))
 
+    if n == 1:
+        # the side blocks below (scaling proxy, other configs, parity) bring contexts of their own, each up to MAX_BATCH_PATHS
+        # slots x 288 B x 3 lanes: this one (172 GB at the default) goes first
+        r.close()
+        r = None
     red_dev = "cpu" if rehearsal else f"cuda:{local_rank}"
     rays = torch.tensor([ctr["rays"], ctr["camera_samples"], ctr["extension_rays"], ctr["extension_hits"],
                          ctr["shadow_rays"], ctr["rays_traced"], ctr["shadow_rays_traced"]], dtype=torch.float64, device=red_dev)
@@ -480,10 +492,11 @@ def main():
                                    "pipeline_model_GBps": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9, 2),
                                    "pipeline_model_frac": round(total_rays / dt * PIPELINE_BYTES_PER_RAY_16x9 / 1e9 / (HBM_PEAK_GBS * n), 5)},
                     "pmc": pmc}
-        if pmc["traffic_bytes_per_launch"] and avg_ms > 0:
-            # the counters' bytes per launch of the same build and batch size (one lane, like this pass) over this pass's launch time
-            g = pmc["traffic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-            roofline["hbm_by_counters"] = {"GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_launch": pmc["traffic_bytes_per_launch"],
+        if pmc["traffic_TBps"]:
+            # the counters' bytes over the dispatch times of the SAME rocprofv3 pass (same build of the kernels, one lane; its launches
+            # hold 32 spp where this run's may hold more: a rate, not a per-launch figure of this run)
+            g = pmc["traffic_TBps"] * 1e3
+            roofline["hbm_by_counters"] = {"GBps": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4), "bytes_per_launch_of_that_pass": pmc["traffic_bytes_per_launch"],
                                            "source": pmc["traffic_source"]}
             roofline["hbm_frac_counters"] = round(g / HBM_PEAK_GBS, 4)
         if pmc["valu"]:
@@ -591,13 +604,15 @@ def main():
                 # parity reported with the metric, at the bench's full frame size: the same 64 spp on the
                 # GPU must be the oracle's framebuffer bit for bit, with equal path counters
                 import numpy as np
-                r.set_device_framebuffer(None, 0)
-                r.clear()
-                r.render_async(0, spp_cpu)
-                gfb = r.framebuffer()
-                gctr = r.counters()
+                rpar = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * 32)
+                par_module = sweep_label(rpar.spec_wait(), rpar.spec_info())["sweep"]   # the kernels the timed region ran (same scene, cached module)
+                for s0 in range(0, spp_cpu, 32):
+                    rpar.render_async(s0, min(s0 + 32, spp_cpu))
+                gfb = rpar.framebuffer()
+                gctr = rpar.counters()
+                rpar.close()
                 same = (gfb.view(np.uint32) == ofb.view(np.uint32)) | (gfb == ofb)
-                parity = {"against": "oracle stream mode, same seed", "size": f"{WIDTH}x{HEIGHT}x{spp_cpu}",
+                parity = {"against": "oracle stream mode, same seed", "size": f"{WIDTH}x{HEIGHT}x{spp_cpu}", "kernels": par_module,
                           "pixel_channels": int(same.size), "mismatched": int((~same).sum()), "tolerance_ulp": 0,
                           "counters_equal": all(gctr[g] == octr[o] for g, o in (
                               ("rays", "rays"), ("extension_rays", "ext_rays"), ("extension_hits", "ext_hits"),
@@ -643,7 +658,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    r.close()
+    if r is not None:
+        r.close()
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ def cut(weights):
     return [x for x in sizes if x > 0]
 
 
-CAP = 66_000_000
+CAP = int(os.environ.get("PT_PLAN_CAP", "66400000"))   # path slots per batch (bench.py MAX_BATCH_PATHS)
 COUNTS = [int(x) for x in os.environ.get("PT_PLAN_COUNTS", "3,4,5,6,9,12,15,18,24,33").split(",")]
 for count in COUNTS:
     sizes = cut([1] * count)
