@@ -538,7 +538,10 @@ def main():
                 rp = pt.Renderer(scene, device=local_rank, seed=0,
                                  max_paths_in_flight=min(max(px * sl for px, sl in zip(pix, plans)), MAX_BATCH_PATHS))
                 rp.spec_wait()
-                render_range(rp, lists[0], 0, plans[0], plans[0])   # warm-up: one launch
+                # warm-up: rank 0's whole pass once, so that EVERY lane's streams have been touched before anything is timed (one
+                # launch warmed lane 0 only and rank 0, timed first, paid the first use of the other lanes' fresh allocations:
+                # +0.6 ms on its 17 ms at K = 20, the slowest "rank" of every round-3 proxy at that K)
+                render_range(rp, lists[0], 0, total_spp, plans[0])
                 rp.wait()
                 times, rr_, cs_, tr_, full_ = [], [], [], [], []
                 for q in range(np_):
