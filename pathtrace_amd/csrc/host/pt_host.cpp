@@ -1054,6 +1054,11 @@ public:
         }
         printf("computed %llu camera rays in %gs, at %g rays per second\n", (unsigned long long)c.camera_samples, dt, c.camera_samples / dt);
         printf("computed %llu rays, at %g rays per second\n", (unsigned long long)c.rays, c.rays / dt);
+        if (ctx) {   // who compiled the traversal kernels this render ran (pt_spec_info): a foreign compiler is correct and slower
+            char info[1024];
+            const int n = pt_spec_info(ctx, info, sizeof info);
+            if (n > 0 && n < (int)sizeof info) printf("per-scene kernels: %s\n", info);
+        }
         if (pth_write_ppm(config.ppm_output_path, framebuffer.data(), config.width, config.height, config.samples, config.exposure))
             throw JsonError(pt_last_error());
     }

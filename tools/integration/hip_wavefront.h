@@ -249,6 +249,12 @@ public:
         pt_counters c;
         pt_get_counters(ctx, &c);                                             // c.rays = total_bounces of renderer.h:696-706
         rays_traced = c.rays;
+        {   // ABI v5: who compiled the traversal kernels this render ran -- a foreign compiler (a host process that carries
+            // another ROCm under the same sonames) builds correct, measurably slower kernels: say so next to the statistics
+            char info[1024];
+            const int n = pt_spec_info(ctx, info, sizeof info);
+            if (n > 0 && n < (int)sizeof info) std::cout << "per-scene kernels: " << info << std::endl;
+        }
         float max_luminance, avg_luminance, total_luminance;                  // unchanged film output, renderer.h:719-727
         calculate_luminance(framebuffer, film.width, film.height, config.samples, film.width * film.height, max_luminance,
                             total_luminance, avg_luminance);

@@ -21,3 +21,4 @@ extern "C" int pt_multi_get_counters(pt_multi *, pt_counters *) { return -1; }
 extern "C" int pt_multi_device_count(pt_multi *) { return 0; }
 extern "C" int pt_multi_get_device_counters(pt_multi *, int32_t, pt_counters *) { return -1; }
 extern "C" uint64_t pt_multi_exchange_bytes(pt_multi *) { return 0; }
+extern "C" int pt_spec_info(pt_ctx *, char *, size_t) { return -1; }
