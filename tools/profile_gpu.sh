@@ -18,7 +18,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 SC=""
 if [ -n "$SCENE" ]; then SC="--scene $R/scenes/$SCENE --no-configs --no-scaling-proxy"; fi
-timeout -k 10 500 python3 "$R/bench.py" $SC > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench.err" || { echo "bench failed"; tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
+timeout -k 10 800 python3 "$R/bench.py" $SC > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench.err" || { echo "bench failed"; tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
 cd /tmp
 Q="--no-cpu-baseline --no-configs --no-scaling-proxy"
 if [ -n "$SCENE" ]; then Q="$Q --scene $R/scenes/$SCENE"; fi
