@@ -1020,6 +1020,22 @@ DEVI void face_fold(float x0, float z0, float x1, float z1, float num, float ox,
 // long as the packed one, tools/microbench/valu_rates.hip -- the scalars d and r enter through op_sel, no moves).  Per
 // component it is fdiv_q_nofix statement for statement.
 typedef float pt_pk2 __attribute__((ext_vector_type(2)));
+DEVI void fdiv_q2_nofix_dd(float n0, float n1, float d0, float d1, float r0, float r1, float &q0, float &q1)
+{   // two independent quotients n0 / d0, n1 / d1 side by side (fdiv_q_nofix per component)
+#if PT_PK_DIV
+    pt_pk2 n; n.x = n0; n.y = n1;
+    pt_pk2 dd; dd.x = d0; dd.y = d1;
+    pt_pk2 rr; rr.x = r0; rr.y = r1;
+    pt_pk2 q = n * rr;
+    pt_pk2 rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    rem = __builtin_elementwise_fma(-dd, q, n);
+    q = __builtin_elementwise_fma(rem, rr, q);
+    q0 = q.x; q1 = q.y;
+#else
+    q0 = fdiv_q_nofix(n0, d0, r0); q1 = fdiv_q_nofix(n1, d1, r1);
+#endif
+}
 DEVI void fdiv_q2_nofix(float n0, float n1, float d, float r, float &q0, float &q1)
 {
 #if PT_PK_DIV
@@ -1076,7 +1092,11 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
     int cur_id[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        inv[r] = V(fdiv(1.0f, B[r].x), fdiv(1.0f, B[r].y), fdiv(1.0f, B[r].z));   // aabb.h:38
+        {   // aabb.h:38: 1 / direction, exact; tame components are finite and non-zero: no fix-up, x and y as a packed pair
+            const float rx = fdiv_rcp(B[r].x), ry = fdiv_rcp(B[r].y), rz = fdiv_rcp(B[r].z);
+            fdiv_q2_nofix_dd(1.0f, 1.0f, B[r].x, B[r].y, rx, ry, inv[r].x, inv[r].y);
+            inv[r].z = fdiv_q_nofix(1.0f, B[r].z, rz);
+        }
         cur_t[r] = lane_valid ? FLT_MAX : -INFINITY;
         cur_id[r] = -1;
         skipf[r] = 0.0f;
