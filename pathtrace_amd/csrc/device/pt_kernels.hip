@@ -78,18 +78,8 @@ namespace ptd {
 #ifndef PT_SKIP_NOOP_RADIANCE
 #define PT_SKIP_NOOP_RADIANCE 1   // radiance updates that cannot change a bit are not performed (0: the A/B)
 #endif
-#ifndef PT_LIGHT_UNROLL
-#define PT_LIGHT_UNROLL 1    // k_shade's light-sample loop of the one-rect-light case: samples in flight per iteration (measurement knob)
-#endif
 #define PT_LIGHT_ONE(P, F, k_) rect_light_sample(PlaneTag<P>{}, BoolTag<F>{}, (k_), base + NV + (k_) * (3u + NV), tl, lq.x0, lq.z0, lq.x1, lq.z1, lq.y)
-#if PT_LIGHT_UNROLL == 2   // two samples per iteration (independent chains side by side), a last one for odd counts
-#define PT_LIGHT_LOOP(P, F) { uint32_t k = 0; for (; k + 1 < L; k += 2) { PT_LIGHT_ONE(P, F, k); PT_LIGHT_ONE(P, F, k + 1); } if (k < L) PT_LIGHT_ONE(P, F, k); }
-#else
 #define PT_LIGHT_LOOP(P, F) for (uint32_t k = 0; k < L; k++) PT_LIGHT_ONE(P, F, k);
-#endif
-#ifndef PT_SHADE_TRIM
-#define PT_SHADE_TRIM 1      // k_shade's light-sample loop: branch-free in-bounds select and "can contribute" test (0: the A/B)
-#endif
 #ifndef PT_SHADE_FDIV
 #define PT_SHADE_FDIV 1      // k_shade's rect-light sample loop divides on pt_fdiv.h's form behind range checks (0: IEEE sequences, the A/B)
 #endif
@@ -2308,7 +2298,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
             // infinities pass through both (ignored by min / max) and need no check: v_div_fixup gives non-finite operands the
             // IEEE result.
             float gmin = 1.0f, gmax = 1.0f;
-            float litacc = 0.0f;   // PT_SHADE_TRIM: largest |c|_1 over the samples staged so far
+            float litacc = 0.0f;   // largest |c.x| + |c.y| + |c.z| over the samples staged so far
             auto emit_sample = [&](auto fast_c, const uint32_t k, v3 ldir, float cos_l, float light_pdf_l) {
                 constexpr bool FAST = decltype(fast_c)::value;
                 const float scatter_pdf_l = material_value_of(mat_type, cos_l);   // cosine_pdf's cosine IS cos_l (pdf.h:20)
@@ -2327,13 +2317,10 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 if (stage) {
                     st_d[k * PT_BLOCK] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                     st_e[k * PT_BLOCK] = make_float2(c.y, c.z);
-#if PT_SHADE_TRIM
                     // "no component NaN and some component non-zero" <=> |c.x| + |c.y| + |c.z| > 0 (the sum is NaN iff a component is;
                     // +inf counts as non-zero): the running maximum ignores NaN sums and is positive iff some sample can contribute
+                    // (round 3: six compares and five mask operations per sample)
                     litacc = fmaxf(litacc, fabsf(c.x) + fabsf(c.y) + fabsf(c.z));
-#else
-                    lit = lit || (!v_is_nan(c) && (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f));
-#endif
                 } else {
                     sq.d[(long long)k * P + o] = make_float4(ldir.x, ldir.y, ldir.z, c.x);
                     sq.e[(long long)k * P + o] = make_float2(c.y, c.z);
@@ -2384,7 +2371,6 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                 const float tq = (fabsf(ds.y) > 0.0f && fabsf(ds.y) < INFINITY) ? 1.0f : NAN;   // ds.y / ds.y
                 const float xh = os.x + tq * ds.x, zh = os.z + tq * ds.z;
                 float light_pdf_l = 0.0f;
-#if PT_SHADE_TRIM
                 if (FAST && !B0) {   // (the bounce-0 instantiation has no register to spare for it: 18 spilled VGPRs)
                     // the quotient is formed for every lane (some lane of the wave needs it anyway) and kept where the reference's
                     // "xh < x0 || xh > x1 || zh < z0 || zh > z1" is false: one maximum decided by its sign, NaN coordinates pass
@@ -2393,9 +2379,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     const float lp = fdiv(d2, cosine_f * area);
                     const float eo = fmaxf(fmaxf(x0 - xh, xh - x1), fmaxf(z0 - zh, zh - z1));
                     light_pdf_l = (eo > 0.0f) ? 0.0f : lp;
-                } else
-#endif
-                if (!(xh < x0 || xh > x1 || zh < z0 || zh > z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
+                } else if (!(xh < x0 || xh > x1 || zh < z0 || zh > z1)) {   // t = 1 or NaN passes 0.001 .. FLT_MAX
                     const float d2 = (tq * vl) * (tq * vl);
                     const float cosine = FAST ? cosine_f : fabsf(ds.y) / vl;
                     light_pdf_l = FAST ? fdiv(d2, cosine * area) : d2 / (cosine * area);
@@ -2508,9 +2492,7 @@ __global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, co
                     light_sample(k, kb, lin, S.prims[lin.prim], false);
                 }
             }
-#if PT_SHADE_TRIM
             if (stage) lit = litacc > 0.0f;
-#endif
         }
         if (stage) {
             o = reserve(shadow && lit, &sq.count[seg_o], 1);
@@ -2750,16 +2732,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
 // ------------------------------------------------------------------------------------------------
 // at most 4096 workgroups per launch (256 CUs x 8 resident x 2: measured better balanced than 2048), few enough to dispatch quickly
 static int g_grid_max = 0;
-static int g_grid_kernel[3] = {0, 0, 0};   // extend, shade, connect: PATHTRACE_HIP_GRID_EXTEND / _SHADE / _CONNECT (measurement knobs), 0 = PATHTRACE_HIP_GRID
-static int persistent_grid(long long chunks, int kernel = -1)
+static int persistent_grid(long long chunks)
 {
-    if (!g_grid_max) {
-        const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096;
-        const char *names[3] = {"PATHTRACE_HIP_GRID_EXTEND", "PATHTRACE_HIP_GRID_SHADE", "PATHTRACE_HIP_GRID_CONNECT"};
-        for (int k = 0; k < 3; k++) { const char *v = getenv(names[k]); g_grid_kernel[k] = v ? atoi(v) : 0; }
-    }
-    const int cap = (kernel >= 0 && g_grid_kernel[kernel] > 0) ? g_grid_kernel[kernel] : g_grid_max;
-    return (int)(chunks < cap ? chunks : cap);
+    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096; }
+    return (int)(chunks < g_grid_max ? chunks : g_grid_max);
 }
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
@@ -2768,7 +2744,7 @@ void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipSt
 void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s, SpecJob *spec)
 {
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * PT_BLOCK * sizeof(float2);
-    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK), 0)), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
     // the scene's own build of the sweep when it is ready (pt_spec.cpp), else -- and on any launch error -- the generic kernel
     if (spec && !S.walk && spec_launch_extend(spec, PT_FUSE_GENERATE && bounce == 0, (int)grid.x, lds, s, S, st, b, qi, bounce) == 0) return;
 #define PT_LAUNCH_EXTEND_B(GA, WALK, B0) hipLaunchKernelGGL((k_extend<GA, WALK, B0>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, qi, bounce)
@@ -2781,7 +2757,7 @@ void launch_extend(const DScene &S, const DStreams &st, const DBatch &b, int qi,
 }
 void launch_shade(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, hipStream_t s)
 {
-    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK), 1)), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg * (b.seg_cap / PT_BLOCK))), block(PT_BLOCK);
     const size_t lds = b.stage_shadow ? (size_t)S.light_samples * PT_BLOCK * (sizeof(float4) + sizeof(float2)) : 0;
 #define PT_LAUNCH_SHADE_B(TEX, LM, B0)                                                                                                   \
     do {                                                                                                                                \
@@ -2811,7 +2787,7 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     if (!spec_connect) spec = nullptr;
     if (spec && !S.walk && L % spec_connect_nr(spec) == 0) nr = spec_connect_nr(spec);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);
-    const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK), 2)), block(PT_BLOCK);
+    const dim3 grid(persistent_grid(b.n_seg_out * (b.seg_cap_out / PT_BLOCK))), block(PT_BLOCK);
     if (spec && !S.walk && nr == spec_connect_nr(spec) && spec_launch_connect(spec, (int)grid.x, lds, s, S, st, b, bounce) == 0) return;
 #define PT_LAUNCH_CONNECT(NR, TEX, GA, WALK) hipLaunchKernelGGL((k_connect<NR, TEX, GA, WALK>), grid, block, lds, s, S, S.ops, S.insts, S.prims, S.mats, S.lights, S.emit, st, b, bounce)
 #define PT_LAUNCH_CONNECT_NR(TEX, GA) { if (nr == 4) PT_LAUNCH_CONNECT(4, TEX, GA, false); else if (nr == 2) PT_LAUNCH_CONNECT(2, TEX, GA, false); else PT_LAUNCH_CONNECT(1, TEX, GA, false); }
