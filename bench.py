@@ -522,7 +522,7 @@ def main():
         proxy = None
         if n == 1 and not args.no_scaling_proxy and not weak:
             proxy = {"note": "every rank's tile list of an N'-rank run rendered on this GPU for the same K steps with that run's launch plan; "
-                             "T1 = this run's timed region; the RCCL framebuffer reduce (33 MB at 1080p) and host-side launch contention "
+                             "T1 = this run's timed region, a rank's time = the better of two passes; the exchange of the owned tiles and host-side launch contention "
                              "between processes are not in it", "T1_ms": round(dt * 1e3, 3), "by_n": []}
             p0 = time.perf_counter()
             costs = costs or tile_costs()
@@ -545,11 +545,15 @@ def main():
                 rp.wait()
                 times, rr_, cs_, tr_, full_ = [], [], [], [], []
                 for q in range(np_):
-                    rp.clear()
-                    t0 = time.perf_counter()
-                    render_range(rp, lists[q], 0, total_spp, plans[q])
-                    rp.wait()
-                    times.append(time.perf_counter() - t0)
+                    best = None
+                    for _rep in range(2):   # the better of two: one stray 3 ms on one "rank" of eight reads as 0.79 instead of 0.94
+                        rp.clear()
+                        t0 = time.perf_counter()
+                        render_range(rp, lists[q], 0, total_spp, plans[q])
+                        rp.wait()
+                        t1 = time.perf_counter() - t0
+                        best = t1 if best is None else min(best, t1)
+                    times.append(best)
                     rr_.append(rp.counters()["rays"])
                     cs_.append(rp.counters()["camera_samples"])
                     tr_.append(rp.counters()["rays_traced"])
