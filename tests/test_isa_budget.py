@@ -29,6 +29,10 @@ BUDGET = {
     "void ptd::k_shade<false, 1, true, false>": (6, 4250, 340, 1780, 4, 120),
     # the bounce-0 instantiation (forms its camera rays; no path record loads): the camera's scalars cost it more spilled SGPRs
     "void ptd::k_shade<false, 1, true, true>": (6, 4200, 340, 1660, 0, 155),
+    # the instantiations that evaluate textures (Perlin noise, image lookups) are built for 5 waves per SIMD: at 6 they kept
+    # 36 - 41 lane values in scratch
+    "void ptd::k_shade<true, 1, true, false>": (5, 6000, 360, 2650, 16, 200),
+    "void ptd::k_shade<true, 1, true, true>": (5, 5850, 360, 2500, 0, 210),
     "ptd::k_generate": (8, 400, 140, 200, 0, 0),
 }
 
