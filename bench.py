@@ -145,7 +145,8 @@ def stream_bytes(kernel, d, light_samples, n_launches, pixels, generate_launches
 
 
 def launch_plan(my_pixels, total_spp):
-    """Samples per pixel of one wavefront launch: as few EQUAL batches as MAX_BATCH_PATHS paths each allow, and at least TWO.
+    """Samples per pixel of one wavefront launch: as few EQUAL batches as MAX_BATCH_PATHS paths each allow, at least TWO, and a
+    multiple of the lanes when there are more batches than lanes.
     Independent of N.  Measured with tools/plan_probe.py: for every N and K the fewest batches win, because every batch pays its
     thin late bounces (30 launches of a few hundred thousand paths) once -- round 3: N = 8, K = 20: 19.2 ms in 3 batches, 20.8 in
     6, 22.8 in 12 (profiles/r03d_launch_plans.jsonl) -- down to two: round 4 (profiles/r04_launch_plans.jsonl, one box) a rank of
@@ -153,6 +154,11 @@ def launch_plan(my_pixels, total_spp):
     overlap with; N = 4 (3 batches) and N = 2 (6) are at their best where the cap puts them."""
     spp_cap = max(1, MAX_BATCH_PATHS // max(my_pixels, 1))
     batches = max(int(os.environ.get("PT_BENCH_TARGET_BATCHES", "2")), -(-total_spp // spp_cap))
+    # more batches than lanes: a multiple of the lanes, so that the last round of batches is a full one (N = 1, K = 20, same box:
+    # 4 batches of 80 spp 133.2 ms, 6 of 54 129.5, 3 of 107 -- a larger cap -- 129.0 to 130.5; K = 64: 11 batches 415.7 ms, 12 413.6;
+    # profiles/r04_launch_plans.jsonl)
+    if batches > N_LANES and not os.environ.get("PT_BENCH_TARGET_BATCHES"):
+        batches = -(-batches // N_LANES) * N_LANES
     want = -(-total_spp // batches)   # equal batches (the last one may be a few samples short)
     if os.environ.get("PT_BENCH_GROUP"):   # measurement knob: steps per launch
         want = SPP_PER_STEP * int(os.environ["PT_BENCH_GROUP"])

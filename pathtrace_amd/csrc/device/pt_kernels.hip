@@ -64,6 +64,9 @@ namespace ptd {
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 6     // waves per SIMD k_shade is compiled for (80 VGPRs)
 #endif
+#ifndef PT_SHADE_WAVES_TEX
+#define PT_SHADE_WAVES_TEX 5   // the instantiations that evaluate textures: 96 VGPRs, 0 - 16 of them spilled instead of 36 - 41 (+1 % on textured_room; 4 waves, no spills: -2 %)
+#endif
 #ifndef PT_CONNECT_WAVES
 #define PT_CONNECT_WAVES 6   // k_connect with two rays per sweep
 #endif
@@ -2016,7 +2019,7 @@ DEVI float material_value_of(int type, float cosine)
 // scalar, per-lane select), 0: any number (per-lane gathers).  Separate instantiations keep the registers of one mode out
 // of the others.
 template <bool TEX, int LM, bool STAGE, bool B0>   // B0: see k_extend
-__global__ __launch_bounds__(PT_BLOCK, PT_SHADE_WAVES) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
+__global__ __launch_bounds__(PT_BLOCK, TEX ? PT_SHADE_WAVES_TEX : PT_SHADE_WAVES) void k_shade(DScene S, const DOp *__restrict__ t_ops, const DInst *__restrict__ t_insts, const DPrim *__restrict__ t_prims,
         const DMat *__restrict__ t_mats, const int32_t *__restrict__ t_lights, const float4 *__restrict__ t_emit, DStreams st, DBatch b, int qi, int bounce)
 {
     // scene tables arrive as separate __restrict__ kernel arguments: only then can hipcc prove that the stream
