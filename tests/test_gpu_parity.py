@@ -250,6 +250,28 @@ def test_more_bounces_than_live_count_words(oracle, scene, max_bounces, spec, mo
     assert np.array_equal(bits(gpu), bits(gpu2)) and gc == gc2
 
 
+@pytest.mark.parametrize("spec", ["off", "sync"])
+def test_production_queue_geometry_in_one_batch(oracle, spec, monkeypatch):
+    # One batch that takes every production-default turn of the queue walk at once: 512 x 512 = 2^18 pixels per sample (a
+    # multiple of 2^16: segments of 4096 + 256 slots, pt_context.cpp render_group), 12 samples in flight = 723 segments (more
+    # than the 512 below which segments stop merging: bounce 0 merges to 362, the later bounces keep them), the permuted segment
+    # walk and the live-count bound -- on the library's kernels and on the scene's per-scene module.
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC", spec)
+    w, h, spp = 512, 512, 12
+    scene = "cornell_box"
+    ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=5)
+    sc = pt.Scene(scene_path(scene), w, h)
+    r = pt.Renderer(sc, seed=5, max_paths_in_flight=w * h * spp)
+    if spec == "sync":
+        assert r.spec_wait() == 1, r.spec_info()
+    gpu = r.render(spp)
+    gc = r.counters()
+    r.close()
+    assert_bit_identical(gpu, ref, f"{scene} 512x512x12 in one batch, PATHTRACE_HIP_SPEC={spec}")
+    assert_counters(gc, oc, scene)
+    assert gc["camera_samples"] == w * h * spp
+
+
 @pytest.mark.parametrize("scene,max_bounces", [("three_orbs", 50), ("light_test", 12), ("cornell_box", 50)])
 def test_tile_costs_equal_traced_rays_when_batches_die_early(scene, max_bounces):
     # pt_measure_tile_costs' contract: a tile's cost = the rays the device traces for it + one per pixel.  Open scenes and
