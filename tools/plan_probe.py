@@ -40,8 +40,10 @@ def cut(weights):
 
 CAP = int(os.environ.get("PT_PLAN_CAP", "66400000"))   # path slots per batch (bench.py MAX_BATCH_PATHS)
 COUNTS = [int(x) for x in os.environ.get("PT_PLAN_COUNTS", "3,4,5,6,9,12,15,18,24,33").split(",")]
-for count in COUNTS:
-    sizes = cut([1] * count)
+WEIGHTS = [[float(x) for x in w.split(":")] for w in os.environ.get("PT_PLAN_WEIGHTS", "").split(",") if w]   # e.g. "5:3,3:5,2:1:1": unequal batches
+for plan in COUNTS + WEIGHTS:
+    count = plan if isinstance(plan, int) else len(plan)
+    sizes = cut([1] * count if isinstance(plan, int) else plan)
     if max(pix) * max(sizes) > CAP or len(sizes) < count:
         continue
     r = pt.Renderer(scene, max_paths_in_flight=max(pix) * max(sizes))
@@ -66,5 +68,5 @@ for count in COUNTS:
         times.append(tt)
     r.close()
     best = [min(a, b) for a, b in zip(*times)]
-    print(json.dumps({"n": n, "steps": steps, "batches": count, "spp": sizes[0], "paths_M": round(max(pix) * sizes[0] / 1e6, 1),
+    print(json.dumps({"n": n, "steps": steps, "batches": count, "spp": sizes[0], "sizes": sizes, "paths_M": round(max(pix) * sizes[0] / 1e6, 1),
                       "max_ms": round(max(best) * 1e3, 3), "sum_ms": round(sum(best) * 1e3, 3), "n_x_max_ms": round(n * max(best) * 1e3, 3)}), flush=True)
