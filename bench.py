@@ -18,8 +18,13 @@ rays per hit, which is what the reference and the CPU baseline perform for the s
 cornell_box, because hits none of whose light samples can contribute get no shadow rays here; its rate is reported
 beside it as `value_reference_equivalent` and is the figure to compare with `cpu_baseline`.
 
-Launch plan (`launch_plan`): a rank's K steps are cut into as few wavefront batches as 199 M paths each allow, at least two
-(measured: the fewest batches win, down to two -- DESIGN.md 6), whatever N and K are.
+Launch plan: the LIBRARY's (include/pathtrace_hip.h "the launch plan", ABI v6).  Contexts are created with
+max_paths_in_flight = 0, `pt_reserve(pixels, spp)` sizes their streams outside the timed region (set-up, like the scene upload)
+and every render is ONE `pt_render_tiles_async` call over all its samples, which the library cuts into as few equal batches as
+199 M paths each allow, at least two, a multiple of its lanes -- the same calls the reference-side plugin makes.  `plugin_path`
+times that plugin surface itself: `pth_main` (main.cpp:108-168 for render_type hip_wavefront, a child process reading a
+config.json) and, when the build container left it, `oracle/_ref/plugin_driver render` (the reference's own Renderer protocol
+over tools/integration/hip_wavefront.h), the rates they print beside `value`.
 
 N > 1 (strong scaling: the frame and its K*16 spp are fixed, the metric is "1080p@1024spp at 1/2/4/8 GPU"): the image is
 partitioned by 128x128 tile in NaiveSpiral order, ownership balanced over per-tile ray counts measured
@@ -60,10 +65,10 @@ SPP_PER_STEP = int(os.environ.get("PT_BENCH_SPP_PER_STEP", "16"))
 TILE = 128
 LIGHT_SAMPLES = 4              # BASELINE configs: light_samples 4 (pt.Renderer's default)
 N_LANES = 3                    # stream lanes of a context (pt_context.cpp; PATHTRACE_HIP_LANES)
-# 199 M path slots x 288 B x 3 lanes = 172 GB of the 288 GB (round 3: 66 M / 57 GB).  Bigger batches, fewer launches: same box, K = 64,
-# 66 M / 133 M / 199 M slots: 39.33 / 39.69 / 39.99 Grays/s (profiles/experiments/r04_ab_runs.json).  48 601 segments of 4096 slots
-# stay below the 2^16 the permuted segment walk multiplies in 32 bits.
-MAX_BATCH_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", str(1920 * 1080 * 96)))
+# Measurement knob only: an EXPLICIT max_paths_in_flight for every context of this run (e.g. 1920*1080*32 = 32 spp per launch for
+# the PMC passes of tools/profile_gpu.sh).  Unset = 0 = the library's launch plan sizes the contexts (PT_PLAN_MAX_PATHS = 199 M
+# slots x 288 B x 3 lanes = 172 GB of the 288 GB; same box, K = 64, 66 M / 133 M / 199 M slots: 39.33 / 39.69 / 39.99 Grays/s).
+EXPLICIT_PATHS = int(os.environ.get("PT_BENCH_MAX_PATHS", "0"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # vector ALU roof: 256 CUs x 4 SIMDs, one wave64 FP32 mul/add/fma every 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
 # v_fma_f32 2 cycles per wave64 = 157.3 TFLOP/s); other vector instruction classes issue at 4 or more cycles
@@ -71,8 +76,9 @@ VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 2
 PIPELINE_BYTES_PER_RAY_16x9 = 153.0         # whole pipeline, cornell_box 16:9
 
 
-# What a vector instruction costs to issue on one SIMD (tools/microbench/valu_rates.hip): classes of tools/isa_stats.py
-ISSUE_CYCLES = {"fp2": 2.0, "fp2s": 4.0, "v4": 4.0, "pk": 4.0, "trans": 8.0}
+# What a vector instruction costs to issue on one SIMD (tools/microbench/valu_rates.hip): the class table of
+# tools/isa_stats.py, which is the one the *_instruction_mix.json summaries' issue_cycles_per_valu were weighted with
+from tools.isa_stats import ISSUE_CYCLES  # noqa: E402
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
@@ -144,27 +150,6 @@ def stream_bytes(kernel, d, light_samples, n_launches, pixels, generate_launches
             "accumulate": 16 * N + 32 * pixels * n_launches}[kernel]
 
 
-def launch_plan(my_pixels, total_spp):
-    """Samples per pixel of one wavefront launch: as few EQUAL batches as MAX_BATCH_PATHS paths each allow, at least TWO, and a
-    multiple of the lanes when there are more batches than lanes.
-    Independent of N.  Measured with tools/plan_probe.py: for every N and K the fewest batches win, because every batch pays its
-    thin late bounces (30 launches of a few hundred thousand paths) once -- round 3: N = 8, K = 20: 19.2 ms in 3 batches, 20.8 in
-    6, 22.8 in 12 (profiles/r03d_launch_plans.jsonl) -- down to two: round 4 (profiles/r04_launch_plans.jsonl, one box) a rank of
-    N = 8 at K = 20 takes 17.6 ms in 2 batches, 18.2 in 3 (round 3's "one per lane") and 18.6 in ONE, whose tail has nothing to
-    overlap with; N = 4 (3 batches) and N = 2 (6) are at their best where the cap puts them."""
-    spp_cap = max(1, MAX_BATCH_PATHS // max(my_pixels, 1))
-    batches = max(int(os.environ.get("PT_BENCH_TARGET_BATCHES", "2")), -(-total_spp // spp_cap))
-    # more batches than lanes: a multiple of the lanes, so that the last round of batches is a full one (N = 1, K = 20, same box:
-    # 4 batches of 80 spp 133.2 ms, 6 of 54 129.5, 3 of 107 -- a larger cap -- 129.0 to 130.5; K = 64: 11 batches 415.7 ms, 12 413.6;
-    # profiles/r04_launch_plans.jsonl)
-    if batches > N_LANES and not os.environ.get("PT_BENCH_TARGET_BATCHES"):
-        batches = -(-batches // N_LANES) * N_LANES
-    want = -(-total_spp // batches)   # equal batches (the last one may be a few samples short)
-    if os.environ.get("PT_BENCH_GROUP"):   # measurement knob: steps per launch
-        want = SPP_PER_STEP * int(os.environ["PT_BENCH_GROUP"])
-    return max(1, min(spp_cap, want))
-
-
 def self_launch(n, argv):
     """Start the N ranks as fresh child processes (this parent never touches the GPU) and relay their exit code."""
     import socket
@@ -195,7 +180,7 @@ def pmc_profile(dom):
     this build of the kernels (kernel_source_sha16 recorded in the file), and under their own key."""
     import glob
     sha = kernel_source_sha16()
-    out = {"kernel_source_sha16": sha, "traffic_bytes_per_launch": None, "traffic_TBps": None, "traffic_source": None, "valu": None,
+    out = {"kernel_source_sha16": sha, "traffic_bytes_per_launch": None, "traffic_TBps": None, "traffic_source": None, "valu": None, "wait_states": None,
            "note": "rocprofv3 --pmc passes of tools/profile_gpu.sh (serialised dispatches), not this run; null = no summary of this build"}
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))   # rNNx tags sort by round
     for f in reversed(tfiles):
@@ -206,8 +191,18 @@ def pmc_profile(dom):
         if d.get("kernel_source_sha16") == sha and dom in d:
             out["traffic_bytes_per_launch"] = d[dom].get("hbm_bytes_per_launch")
             out["traffic_seconds_per_launch"] = d[dom].get("seconds_per_launch")
-            out["traffic_TBps"] = d[dom].get("TBps")   # bytes and seconds of the SAME pass (its launches hold 32 spp: PT_BENCH_GROUP=2)
+            out["traffic_TBps"] = d[dom].get("TBps")   # bytes and seconds of the SAME pass (its launches hold 32 spp: PT_BENCH_MAX_PATHS = 1920*1080*32)
             out["traffic_source"] = "profiles/" + os.path.basename(f)
+            break
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_wait_states.json")))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel_source_sha16") == sha and dom in d and "cfg" not in os.path.basename(f) and "textured" not in os.path.basename(f):
+            w = d[dom]
+            out["wait_states"] = {"parked": w.get("parked_on_waitcnt_or_barrier"), "stalled_at_issue": w.get("stalled_at_issue"), "executing": w.get("executing"),
+                                  "resident_waves_per_simd": w.get("resident_waves_per_simd"), "source": "profiles/" + os.path.basename(f)}
             break
     for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_instruction_mix.json")))):
         try:
@@ -235,23 +230,98 @@ def sweep_label(spec_state, info):
             "note": info.get("note")}
 
 
+def plugin_path(scene_file, w, h, spp, fb_timed, value_traced, with_reference_side):
+    """The drop-in surface timed as a user of the reference gets it: config.json in, rays per second out.
+    (a) `pth_main` (pt_host.cpp: main.cpp:108-168 for render_type "hip_wavefront") in a child process of its own;
+    (b) `oracle/_ref/plugin_driver render`: the REFERENCE's Renderer protocol (its constructor, start_render -> sync_progress*
+        -> finalize, its film output) over tools/integration/hip_wavefront.h, built in the build container against the reference's
+        headers (the binary travels, the sources do not), when present; its framebuffer is held against this run's, bit for bit.
+    Both pass max_paths_in_flight = 0 and make ONE pt_render_async call: the launch plan is the library's.  The rates are the ones
+    the programs print themselves (renderer.h:700-706's lines), on the library's clock of the render call."""
+    import re
+    import tempfile
+    import numpy as np
+    out = {"workload": f"scenes/{os.path.basename(scene_file)} {w}x{h}x{spp}spp, config.json -> render_type hip_wavefront, max_paths_in_flight 0 (the library's launch plan)",
+           "value_of_this_run": value_traced}
+
+    def rates(txt):
+        d = {}
+        m = re.search(r"time taken to compute ([0-9.eE+-]+)", txt)
+        d["seconds"] = float(m.group(1)) if m else None
+        m = re.search(r"polling included: ([0-9.eE+-]+)", txt)
+        d["seconds_process_clock"] = float(m.group(1)) if m else None
+        m = re.search(r"computed (\d+) rays, at ([0-9.eE+-]+) rays per second", txt)
+        d["rays"], d["Mrays_per_s_reference_count"] = (int(m.group(1)), round(float(m.group(2)) / 1e6, 2)) if m else (None, None)
+        m = re.search(r"traced (\d+) rays, at ([0-9.eE+-]+) rays per second", txt)
+        d["rays_traced"], d["value"] = (int(m.group(1)), round(float(m.group(2)) / 1e6, 2)) if m else (None, None)
+        m = re.search(r"launch plan: (\d+) batches of (\d+) spp", txt)
+        d["launch_plan"] = {"batches": int(m.group(1)), "spp_per_batch": int(m.group(2))} if m else None
+        d["vs_value"] = round(d["value"] / value_traced, 4) if d["value"] and value_traced else None
+        return d
+
+    with tempfile.TemporaryDirectory() as wd:
+        os.makedirs(os.path.join(wd, "output"))
+        cfg = {"film": {"width": w, "height": h, "gamma": 2.2, "exposure": 0.0}, "ppm_output_path": "output/render.ppm", "png_output_path": "output/render.png",
+               "traced_paths_output_path": "output/out.txt", "traced_paths_2d_output_path": "output/out_2d.txt", "scene": os.path.abspath(scene_file),
+               "should_trace_paths": False, "block_width": 128, "block_height": 128, "render_type": "hip_wavefront",
+               "integrator_type": "iterative nee path tracing", "max_bounces": 10, "samples": spp, "threads": 1, "normal_offset": 0.0001,
+               "light_samples": LIGHT_SAMPLES, "russian_roulette": True, "only_direct_illumination": False}
+        with open(os.path.join(wd, "config.json"), "w") as f:
+            json.dump(cfg, f)
+        code = "import sys; sys.path.insert(0, %r); import pathtrace_amd as pt; rc = pt.lib().pth_main(%r.encode()); sys.stdout.flush(); print('ERR ' + pt.last_error()) if rc else None; sys.exit(1 if rc else 0)" % (ROOT, wd)
+        try:
+            t0 = time.perf_counter()
+            cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+            out["pth_main"] = dict(rates(cp.stdout), process_s=round(time.perf_counter() - t0, 2), rc=cp.returncode)
+            if cp.returncode:
+                out["pth_main"]["error"] = (cp.stdout + cp.stderr)[-400:]
+        except Exception as e:
+            out["pth_main"] = {"error": str(e)[:300]}
+        drv = os.path.join(ROOT, "oracle", "_ref", "plugin_driver")
+        if with_reference_side and os.path.exists(drv):
+            try:
+                from oracle import scene_params
+                params = os.path.join(wd, "params.txt")
+                with open(params, "w") as f:
+                    f.write(scene_params.to_text(scene_params.load_scene_params(scene_file)))
+                fbf = os.path.join(wd, "fb.f32")
+                t0 = time.perf_counter()
+                cp = subprocess.run([drv, params, "render", str(w), str(h), str(spp), "10", str(LIGHT_SAMPLES), "1", "0.0001", "0", "128", "128", fbf],
+                                    capture_output=True, text=True, timeout=600, cwd=wd)
+                d = dict(rates(cp.stdout), process_s=round(time.perf_counter() - t0, 2), rc=cp.returncode)
+                if cp.returncode == 0 and fb_timed is not None:
+                    pfb = np.fromfile(fbf, np.float32).reshape(h, w, 3)
+                    same = (pfb.view(np.uint32) == fb_timed.view(np.uint32)) | (pfb == fb_timed)
+                    d["framebuffer_vs_this_run"] = {"pixel_channels": int(same.size), "mismatched": int((~same).sum()), "tolerance_ulp": 0}
+                elif cp.returncode:
+                    d["error"] = (cp.stdout + cp.stderr)[-400:]
+                out["reference_side_plugin"] = d
+            except Exception as e:
+                out["reference_side_plugin"] = {"error": str(e)[:300]}
+        else:
+            out["reference_side_plugin"] = None
+    best = [v for v in (out.get("pth_main", {}).get("value"), (out.get("reference_side_plugin") or {}).get("value")) if v]
+    out["value"] = min(best) if best else None   # the slower of the two surfaces
+    out["vs_value"] = round(out["value"] / value_traced, 4) if best and value_traced else None
+    out["unit"] = "Mrays/s traced"
+    return out
+
+
 def sub_config(pt, name, scene_file, w, h, spp_step, steps, device, oracle=None):
     """Another BASELINE configuration on this GPU: Mrays/s (unprofiled, `steps` steps), rays per camera sample, and the
     kernel times of a short serialised pass (one lane)."""
     scene = pt.Scene(os.path.join(ROOT, "scenes", scene_file), w, h)
     total = spp_step * steps
-    spp_launch = launch_plan(w * h, total)
-    r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=min(w * h * spp_launch, MAX_BATCH_PATHS))
+    r = pt.Renderer(scene, device=device, seed=0, max_paths_in_flight=EXPLICIT_PATHS)
+    r.reserve(w * h, total)   # the library's launch plan sizes the streams (set-up, outside the timed region)
     spec = r.spec_wait()   # the scene's own build of the traversal kernels (hiprtc at pt_create); -1 = generic kernels
 
     def run(s0, s1):
-        s = s0
-        while s < s1:
-            e = min(s + spp_launch, s1)
-            r.render_async(s, e)
-            s = e
-    run(0, spp_launch)
+        r.render_async(s0, s1)   # ONE call: the library cuts it into batches
+    run(0, total)
     r.wait()
+    plan = r.plan()
+    spp_launch = plan["spp_per_batch"]
     r.clear()
     t0 = time.perf_counter()
     run(0, total)
@@ -287,11 +357,12 @@ def sub_config(pt, name, scene_file, w, h, spp_step, steps, device, oracle=None)
     r.close()
     scene.close()
     return {"config": name, "parity": parity, "module": sweep_label(spec, info), "workload": f"scenes/{scene_file} {w}x{h}, {steps} steps of {spp_step} spp, {spp_launch} spp per launch",
+            "plan": plan,
             "value": round(c["rays_traced"] / dt / 1e6, 2), "value_reference_equivalent": round(c["rays"] / dt / 1e6, 2), "unit": "Mrays/s",
             "rays_per_sample": round(c["rays"] / max(c["camera_samples"], 1), 4),
             "traced_share": round(c["rays_traced"] / max(c["rays"], 1), 4), "ms_per_step": round(dt / steps * 1e3, 4),
             "dominant_kernel": "k_" + dom, "sweep": sweep_label(spec, info)["sweep"],
-            "kernel_ms_serialised_one_launch": {k: round(v["ms"], 3) for k, v in kt.items()}}
+            "kernel_ms_serialised_pass": dict({k: round(v["ms"], 3) for k, v in kt.items()}, spp=spp_launch, lanes=1)}
 
 
 def main():
@@ -302,6 +373,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true")
     ap.add_argument("--no-scaling-proxy", action="store_true")
+    ap.add_argument("--no-plugin-path", action="store_true")
     ap.add_argument("--scene", default=SCENE)
     args = ap.parse_args()
 
@@ -345,7 +417,7 @@ def main():
     def tile_costs():
         # scheduling set-up, like the scene upload outside the timed region: one pass of one sample per pixel over the
         # frame counts the rays of every tile (identical integers on every rank -> the same ownership map everywhere)
-        planner = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=min(WIDTH * HEIGHT, MAX_BATCH_PATHS))
+        planner = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=EXPLICIT_PATHS)
         c = measure_tile_costs(planner, spiral)
         planner.close()
         return c
@@ -368,8 +440,12 @@ def main():
     #   weak:             per-GPU work fixed -- every step renders 16*N spp over the frame
     total_spp = SPP_PER_STEP * args.steps * (n if weak else 1)
     my_pixels = sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in my_tiles)
-    spp_launch = launch_plan(my_pixels, total_spp)
-    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=min(my_pixels * spp_launch, MAX_BATCH_PATHS))
+    # max_paths_in_flight = 0: the library's launch plan sizes the context (what the plugin surface does); pt_reserve here is
+    # set-up like the scene upload -- the first render call would do it otherwise, inside the timed region
+    r = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=EXPLICIT_PATHS)
+    r.reserve(my_pixels, total_spp)
+    plan0 = r.plan()
+    spp_launch = plan0["spp_per_batch"]
     # pt_create started the per-scene build of the traversal kernels (hiprtc, ~2 s, like the scene upload outside the timed
     # region); wait for it so that every timed launch runs the same kernels.  -1: not available, the generic kernels run.
     spec_state = r.spec_wait()
@@ -378,12 +454,8 @@ def main():
     fb = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
     r.set_device_framebuffer(fb.data_ptr(), fb.numel() * 4)
 
-    def render_range(rr, tiles, s0, s1, step):
-        s = s0
-        while s < s1:
-            e = min(s + step, s1)
-            rr.render_tiles_async(tiles, s, e)
-            s = e
+    def render_range(rr, tiles, s0, s1):
+        rr.render_tiles_async(tiles, s0, s1)   # ONE call over all the samples: the library's plan cuts it into wavefront batches
 
     def sync():
         r.wait()
@@ -408,7 +480,7 @@ def main():
         r.clear()
         sync()
         t0 = time.perf_counter()
-        render_range(r, my_tiles, 0, spp, spp_launch)
+        render_range(r, my_tiles, 0, spp)
         r.wait()
         exchange_fb()   # the one exchange of the path; no-op at N = 1
         sync()
@@ -416,7 +488,7 @@ def main():
 
     warm_spp = SPP_PER_STEP * args.warmup * (n if weak else 1)
     if warm_spp:
-        render_range(r, my_tiles, 0, warm_spp, spp_launch)
+        render_range(r, my_tiles, 0, warm_spp)
     sync()
     if dist is not None and not rehearsal and args.warmup > 0:
         exchange_fb()   # untimed: RCCL sets its rings and kernels up on the first collective of this shape
@@ -426,7 +498,11 @@ def main():
     r.set_profiling(False)
     dt = timed_pass(total_spp)
     ctr = r.counters()
+    plan = r.plan()   # how the library cut the timed call
+    lib_seconds = r.render_seconds()   # the library's own clock of that call: entry -> the device finishing its last batch
     fb_sum = float(fb[..., :3].double().sum().item()) if rank == 0 else 0.0
+    fb_timed = fb[..., :3].cpu().numpy().copy() if (rank == 0 and n == 1) else None   # held against the plugin surface's framebuffer below
+    dt_again = timed_pass(total_spp)   # a second pass of the same K steps: the scaling proxy's T1 uses the better of the two, like its ranks
     # ---- the same K steps again with HIP events around every launch, three batches in flight (shared-chip figures) ----
     r.set_profiling(True)
     dt_prof = timed_pass(total_spp)
@@ -443,8 +519,8 @@ def main():
     r.set_lanes(N_LANES if not os.environ.get("PATHTRACE_HIP_LANES") else int(os.environ["PATHTRACE_HIP_LANES"]))
 
     if n == 1:
-        # the side blocks below (scaling proxy, other configs, parity) bring contexts of their own, each up to MAX_BATCH_PATHS
-        # slots x 288 B x 3 lanes: this one (172 GB at the default) goes first
+        # the side blocks below (plugin surface, scaling proxy, other configs, parity) bring contexts of their own, each sized by the
+        # library for its job (up to 199 M slots x 288 B x 3 lanes): this one (172 GB at the default) goes first
         r.close()
         r = None
     red_dev = "cpu" if rehearsal else f"cuda:{local_rank}"
@@ -514,7 +590,18 @@ def main():
                 roofline["issue_model"] = {"wave_insts_per_s": pmc["valu"]["wave_insts_per_s"], "issue_cycles_per_valu_inst": cyc,
                                            "class_cycles": ISSUE_CYCLES, "simd_cycles_per_s": SIMDS * CLOCK_HZ, "source": pmc["valu"]["source"]}
         hbm_real = roofline["hbm_frac_counters"] if roofline["hbm_frac_counters"] is not None else roofline["hbm_frac_stream"]
-        if roofline["issue_frac"] is not None:
+        ws = pmc.get("wait_states")
+        if ws:
+            roofline["parked"] = ws["parked"]
+            roofline["wave_life"] = ws
+        if ws and ws["parked"] is not None and ws["parked"] > (ws["stalled_at_issue"] or 0) + (ws["executing"] or 0):
+            # a wave of this kernel spends more of its life parked on s_waitcnt (memory / atomic / LDS round trips in front of the
+            # next dependent instruction) than stalled at issue and executing together: bound by its latency chains, whatever
+            # the issue and byte fractions read (removing a quarter of k_shade's vector instructions did not shorten it)
+            roofline["bound"] = "latency"
+            roofline["bound_basis"] = "parked on s_waitcnt %.2f of a wave's life against %.2f stalled at issue + %.2f executing (%s); issue_frac %s, %.2f of the HBM roof" % (
+                ws["parked"], ws["stalled_at_issue"], ws["executing"], ws["source"], roofline["issue_frac"], hbm_real)
+        elif roofline["issue_frac"] is not None:
             roofline["bound"] = "valu-issue" if roofline["issue_frac"] >= hbm_real else "hbm"
             roofline["bound_basis"] = "issue_frac %.2f against %.2f of the HBM roof (%s)" % (
                 roofline["issue_frac"], hbm_real, "counters" if roofline["hbm_frac_counters"] is not None else "this implementation's record bytes")
@@ -524,12 +611,21 @@ def main():
             roofline["bound"] = "hbm" if hbm_real >= 0.6 else "valu-issue"
             roofline["bound_basis"] = "inferred (no PMC pass of this build of the kernels): the kernel's own records move %.2f of the HBM roof" % hbm_real
 
+        # ---- the plugin surface itself, same frame and samples as the timed region ----
+        plug = None
+        if n == 1 and not weak and not args.no_plugin_path:
+            try:
+                plug = plugin_path(args.scene, WIDTH, HEIGHT, total_spp, fb_timed, round(traced_rays / dt / 1e6, 2), not args.no_cpu_baseline)
+            except Exception as e:   # the headline number does not depend on it
+                plug = {"error": str(e)[:300]}
+        fb_timed = None
+
         # ---- strong-scaling proxy on this one GPU (the render has no communication: rank r's time here is rank r's time at N) ----
         proxy = None
         if n == 1 and not args.no_scaling_proxy and not weak:
             proxy = {"note": "every rank's tile list of an N'-rank run rendered on this GPU for the same K steps with that run's launch plan; "
-                             "T1 = this run's timed region, a rank's time = the better of two passes; the exchange of the owned tiles and host-side launch contention "
-                             "between processes are not in it", "T1_ms": round(dt * 1e3, 3), "by_n": []}
+                             "T1 and a rank's time = the better of two passes each (same estimator); the exchange of the owned tiles and host-side launch contention "
+                             "between processes are not in it", "T1_ms": round(min(dt, dt_again) * 1e3, 3), "T1_passes_ms": [round(dt * 1e3, 3), round(dt_again * 1e3, 3)], "by_n": []}
             p0 = time.perf_counter()
             costs = costs or tile_costs()
             proxy["planner_ms"] = round((time.perf_counter() - p0) * 1e3, 1)
@@ -540,14 +636,14 @@ def main():
                 strat = os.environ.get("PT_BENCH_PARTITION", "lpt")
                 lists = [tiles_for_rank(WIDTH, HEIGHT, TILE, TILE, q, np_, None if strat == "rr" else costs, strat) for q in range(np_)]
                 pix = [sum((x1 - x0) * (y1 - y0) for (x0, y0, x1, y1) in tl) for tl in lists]
-                plans = [launch_plan(px, total_spp) for px in pix]
-                rp = pt.Renderer(scene, device=local_rank, seed=0,
-                                 max_paths_in_flight=min(max(px * sl for px, sl in zip(pix, plans)), MAX_BATCH_PATHS))
+                rp = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=EXPLICIT_PATHS)
+                rp.reserve(max(pix), total_spp)   # every "rank" gets the library's plan for its own pixels; the streams fit the largest
                 rp.spec_wait()
+                plans = []
                 # warm-up: rank 0's whole pass once, so that EVERY lane's streams have been touched before anything is timed (one
                 # launch warmed lane 0 only and rank 0, timed first, paid the first use of the other lanes' fresh allocations:
                 # +0.6 ms on its 17 ms at K = 20, the slowest "rank" of every round-3 proxy at that K)
-                render_range(rp, lists[0], 0, total_spp, plans[0])
+                render_range(rp, lists[0], 0, total_spp)
                 rp.wait()
                 times, rr_, cs_, tr_, full_ = [], [], [], [], []
                 for q in range(np_):
@@ -555,11 +651,12 @@ def main():
                     for _rep in range(2):   # the better of two: one stray 3 ms on one "rank" of eight reads as 0.79 instead of 0.94
                         rp.clear()
                         t0 = time.perf_counter()
-                        render_range(rp, lists[q], 0, total_spp, plans[q])
+                        render_range(rp, lists[q], 0, total_spp)
                         rp.wait()
                         t1 = time.perf_counter() - t0
                         best = t1 if best is None else min(best, t1)
                     times.append(best)
+                    plans.append(rp.plan()["spp_per_batch"])
                     rr_.append(rp.counters()["rays"])
                     cs_.append(rp.counters()["camera_samples"])
                     tr_.append(rp.counters()["rays_traced"])
@@ -567,7 +664,7 @@ def main():
                         full_.append(dict(rp.counters(), tiles=len(lists[q]), pixels=pix[q]))
                 rp.close()
                 proxy["by_n"].append({"n": np_, "max_rank_ms": round(max(times) * 1e3, 3), "min_rank_ms": round(min(times) * 1e3, 3),
-                                      "predicted_efficiency": round(dt / (np_ * max(times)), 4),
+                                      "predicted_efficiency": round(min(dt, dt_again) / (np_ * max(times)), 4),
                                       "rays_traced_max_over_mean": round(max(tr_) / (sum(tr_) / np_), 4),
                                       "spp_per_launch": plans, "batches_per_rank": [-(-total_spp // sl) for sl in plans],
                                       "rank_ms": [round(t * 1e3, 3) for t in times], "rank_rays": rr_, "rank_camera_samples": cs_, "rank_rays_traced": tr_, "rank_detail": full_ or None,
@@ -617,10 +714,9 @@ def main():
                 # parity reported with the metric, at the bench's full frame size: the same 64 spp on the
                 # GPU must be the oracle's framebuffer bit for bit, with equal path counters
                 import numpy as np
-                rpar = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=WIDTH * HEIGHT * 32)
+                rpar = pt.Renderer(scene, device=local_rank, seed=0, max_paths_in_flight=EXPLICIT_PATHS)
                 par_module = sweep_label(rpar.spec_wait(), rpar.spec_info())["sweep"]   # the kernels the timed region ran (same scene, cached module)
-                for s0 in range(0, spp_cpu, 32):
-                    rpar.render_async(s0, min(s0 + 32, spp_cpu))
+                rpar.render_async(0, spp_cpu)
                 gfb = rpar.framebuffer()
                 gctr = rpar.counters()
                 rpar.close()
@@ -649,7 +745,9 @@ def main():
             "config": {"workload": f"scenes/{os.path.basename(args.scene)} {WIDTH}x{HEIGHT}, iterative NEE path tracing, max_bounces 10, "
                                    f"light_samples 4, russian roulette; step = {SPP_PER_STEP} spp over the frame"
                                    + (f" x {n} (weak)" if weak else "") + f" (K=64 is 1024 spp), {spp_launch} spp per launch on rank 0 "
-                                   f"({-(-total_spp // spp_launch)} launches)",
+                                   f"({plan['batches']} batches, cut by the library)",
+                       "launch_plan": dict(plan, decided_by="libpathtrace_hip.so (pt_render_tiles_async; include/pathtrace_hip.h, ABI v6)" if not EXPLICIT_PATHS else "PT_BENCH_MAX_PATHS (explicit max_paths_in_flight; the library's rule cuts within it)"),
+                       "library_clock_ms": round(lib_seconds * 1e3, 3) if lib_seconds and lib_seconds > 0 else None,
                        "spp_total": total_spp, "camera_samples": int(total_samples), "rays": int(total_rays), "rays_traced": int(traced_rays),
                        "rays_per_sample": round(total_rays / max(total_samples, 1), 4),
                        "E_H_S_per_sample": [round(E / total_samples, 4), round(H / total_samples, 4), round(S / total_samples, 4)],
@@ -662,6 +760,7 @@ def main():
                        "exchange": None if n == 1 else ("gather of owned tiles: %d bytes to rank 0" % exchange.bytes_moved() if exchange else "sum-reduce of whole frames"),
                        "knobs": knobs},
             "roofline": roofline,
+            "plugin_path": plug,
             "scaling_proxy": proxy,
             "configs": configs,
             "cpu_baseline": cpu,

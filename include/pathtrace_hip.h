@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
@@ -115,8 +115,37 @@ typedef struct pt_config {     /* the Config fields the path reads (config.h:74-
     float normal_offset;       /* integrator.h:274 */
     uint32_t seed;             /* stream RNG seed (the reference has one fixed mt19937 seed) */
     int32_t device;            /* HIP device ordinal, -1 = current device */
-    int64_t max_paths_in_flight; /* batch size in camera samples, 0 = default (8 Mi) */
+    int64_t max_paths_in_flight; /* path slots of one wavefront batch.  0 (what a plugin passes) = the library sizes the
+                                  * context itself: the LAUNCH PLAN below, from the pixels and samples of the render calls
+                                  * and the free HBM of the device (ABI v6; up to v5: a fixed 8 Mi) */
 } pt_config;
+
+/* ---- the launch plan (ABI v6) ------------------------------------------------------------------------------
+ * Tiled::start_render (renderer.h:553-603) fans the whole job out at full speed from config.json alone; so does
+ * pt_render_async.  A render call of `pixels` pixels x `samples` samples per pixel is cut into wavefront batches by
+ * one rule, measured on MI355X: as FEW EQUAL batches as the path slots allow, at least TWO (a single
+ * batch's thin late bounces have nothing to overlap with), and a multiple of the context's stream lanes when there are
+ * more batches than lanes (the last round of batches is then a full one).  With max_paths_in_flight = 0 the slots are
+ * the library's to choose: pixels x samples-per-batch of that plan, capped at PT_PLAN_MAX_PATHS and at
+ * PT_PLAN_HBM_FRACTION of the device memory free when the streams are allocated ((192 + 24 light_samples) bytes per slot
+ * and lane).  The streams are allocated by the first render call (or by pt_reserve, which a plugin calls from its
+ * constructor so that the allocation stays out of the timed render) and GROW when a later call's plan wants more; they
+ * never shrink.  With max_paths_in_flight > 0 the caller's size stands and the same rule cuts the calls within it. */
+#define PT_PLAN_MAX_PATHS 199065600ll      /* 1920 x 1080 x 96: 48 601 segments of 4096 slots; 172 GB at 3 lanes */
+#define PT_PLAN_HBM_FRACTION 0.70
+typedef struct pt_plan {
+    int64_t pixels;            /* of the render call (or pt_reserve) the plan was last made for */
+    int32_t samples;           /* samples per pixel of that call */
+    int32_t spp_per_batch;     /* samples per pixel of one wavefront batch */
+    int32_t batches;           /* batches the call was cut into */
+    int32_t lanes;             /* stream lanes the batches rotate over */
+    int64_t paths_per_batch;   /* pixels x spp_per_batch */
+    int64_t path_slots;        /* slots every lane's streams hold now */
+    int64_t stream_bytes;      /* device memory of the wavefront streams, all lanes */
+    int64_t hbm_free_bytes;    /* hipMemGetInfo's free bytes when the streams were last sized */
+    int32_t auto_sized;        /* 1: max_paths_in_flight = 0, the library chose path_slots */
+    int32_t grown;             /* times the streams were re-allocated larger */
+} pt_plan;
 
 /* reference counters: rays = World::hit queries (integrator.h:192,247; renderer.h:696-706) */
 typedef struct pt_counters {
@@ -156,6 +185,23 @@ int pt_render_async(pt_ctx *ctx, int32_t x0, int32_t y0, int32_t x1, int32_t y1,
  * wavefront batch: rects = n_rects * {x0, y0, x1, y1}.  This is how one GPU renders the tiles it owns in a
  * tile-partitioned multi-GPU render without paying one small batch per tile. */
 int pt_render_tiles_async(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end);
+/* ABI v6.  Size (or grow) the wavefront streams for render calls of `pixels` pixels x `samples` samples per pixel, by the
+ * launch plan above; what Renderer::Renderer's framebuffer allocation (renderer.h:121-133) is to the reference.  Optional:
+ * the first render call does it otherwise, inside the caller's timed region.  Returns 0, < 0 on failure. */
+int pt_reserve(pt_ctx *ctx, int64_t pixels, int32_t samples);
+/* The plan of the last render call / pt_reserve and the state of the streams. */
+int pt_get_plan(pt_ctx *ctx, pt_plan *out);
+/* The rule itself (host only, no device): samples per batch of a call of pixels x samples with `path_slots` slots per batch on
+ * `lanes` lanes; *batches (optional) = how many batches that makes. */
+int32_t pt_plan_batches(int64_t pixels, int32_t samples, int64_t path_slots, int32_t lanes, int32_t *batches);
+/* Wall seconds of the last render call: from its entry into pt_render_async / pt_render_tiles_async to the moment the
+ * device finished its last batch (a host function enqueued behind it stamps the clock), i.e. what a caller polling
+ * without delay would measure -- Tiled::finalize's "time taken to compute" (renderer.h:700-706) without the 0.5 s
+ * granularity of main.cpp:158-163's loop.  < 0 while the call is still running or before any call. */
+double pt_render_seconds(pt_ctx *ctx);
+/* Block until everything enqueued has finished or `timeout_ms` have passed (the sleep of main.cpp:162 that ends early):
+ * 1 = idle, 0 = timed out, < 0 error. */
+int pt_wait_for(pt_ctx *ctx, int32_t timeout_ms);
 /* Non-blocking progress (Tiled::sync_progress renderer.h:605-620 reads samples_done[]):
  * returns 1 when everything enqueued so far has finished, 0 if still running, < 0 on error. */
 int pt_poll(pt_ctx *ctx, uint64_t *samples_done, uint64_t *rays_done);
@@ -235,6 +281,11 @@ pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, i
                           int32_t block_w, int32_t block_h);
 void pt_multi_destroy(pt_multi *m);
 int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp_end);
+/* ABI v6: pt_reserve for every device's share of the film; seconds from pt_multi_render_async's entry until the last
+ * device finished (< 0 while running); timed wait (1 idle, 0 timed out). */
+int pt_multi_reserve(pt_multi *m, int32_t samples);
+double pt_multi_render_seconds(pt_multi *m);
+int pt_multi_wait_for(pt_multi *m, int32_t timeout_ms);
 int pt_multi_poll(pt_multi *m, uint64_t *samples_done, uint64_t *rays_done);      /* 1 done, 0 running, < 0 error */
 int pt_multi_wait(pt_multi *m);
 int pt_multi_read_framebuffer(pt_multi *m, float *rgb_sum);                        /* height*width*3, row 0 = bottom row */

@@ -83,6 +83,16 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class Plan(C.Structure):
+    """pt_plan (ABI v6): how the library cut the last render call into wavefront batches, and the state of the streams."""
+    _fields_ = [("pixels", C.c_int64), ("samples", C.c_int32), ("spp_per_batch", C.c_int32), ("batches", C.c_int32), ("lanes", C.c_int32),
+                ("paths_per_batch", C.c_int64), ("path_slots", C.c_int64), ("stream_bytes", C.c_int64), ("hbm_free_bytes", C.c_int64),
+                ("auto_sized", C.c_int32), ("grown", C.c_int32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_uint64 * 5), ("ms", C.c_double * 5), ("units", C.c_uint64 * 5)]
 
@@ -99,7 +109,8 @@ class HostConfig(C.Structure):
 
 
 # every symbol include/pathtrace_hip.h declares
-EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
+EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_reserve", "pt_get_plan", "pt_plan_batches", "pt_render_seconds", "pt_wait_for",
+           "pt_multi_reserve", "pt_multi_render_seconds", "pt_multi_wait_for", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header", "pt_spec_status", "pt_spec_wait", "pt_spec_info", "pt_spec_build_check", "pt_spec_build_info",
            "pt_read_last_batch_radiance", "pt_trace_rays", "pt_last_error", "pt_abi_version", "pt_device_count",
@@ -128,6 +139,17 @@ def lib():
     L.pt_destroy.restype = None
     L.pt_render_async.argtypes = [vp] + [C.c_int32] * 6
     L.pt_render_tiles_async.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32]
+    L.pt_reserve.argtypes = [vp, C.c_int64, C.c_int32]
+    L.pt_get_plan.argtypes = [vp, C.POINTER(Plan)]
+    L.pt_plan_batches.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int32)]
+    L.pt_plan_batches.restype = C.c_int32
+    L.pt_render_seconds.argtypes = [vp]
+    L.pt_render_seconds.restype = C.c_double
+    L.pt_wait_for.argtypes = [vp, C.c_int32]
+    L.pt_multi_reserve.argtypes = [vp, C.c_int32]
+    L.pt_multi_render_seconds.argtypes = [vp]
+    L.pt_multi_render_seconds.restype = C.c_double
+    L.pt_multi_wait_for.argtypes = [vp, C.c_int32]
     L.pt_poll.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.pt_wait.argtypes = [vp]
     L.pt_read_framebuffer.argtypes = [vp, fp]
@@ -300,6 +322,16 @@ def load_config(path: str = None, text: str = None) -> HostConfig:
     return hc
 
 
+def plan_batches(pixels: int, samples: int, path_slots: int, lanes: int = 3):
+    """The library's launch plan rule (host only): (samples per batch, batches) of a call of pixels x samples."""
+    nb = C.c_int32()
+    spp = lib().pt_plan_batches(int(pixels), int(samples), int(path_slots), int(lanes), C.byref(nb))
+    return int(spp), int(nb.value)
+
+
+PLAN_MAX_PATHS = 1920 * 1080 * 96   # PT_PLAN_MAX_PATHS of include/pathtrace_hip.h
+
+
 def spiral_tiles(width, height, bw, bh):
     n = _check(lib().pth_spiral_tiles(width, height, bw, bh, None, 0), "pth_spiral_tiles")
     buf = (C.c_int32 * (4 * n))()
@@ -340,6 +372,24 @@ class Renderer:
         flat = [int(v) for r in rects for v in r]
         arr = (C.c_int32 * len(flat))(*flat)
         _check(lib().pt_render_tiles_async(self._h, len(rects), arr, spp_begin, spp_end), "pt_render_tiles_async")
+
+    def reserve(self, pixels: int, samples: int):
+        """Size the wavefront streams for render calls of pixels x samples by the library's launch plan (pt_reserve):
+        set-up, like the scene upload; the first render call does it otherwise."""
+        _check(lib().pt_reserve(self._h, int(pixels), int(samples)), "pt_reserve")
+
+    def plan(self) -> dict:
+        """The library's launch plan of the last render call / reserve (pt_get_plan)."""
+        p = Plan()
+        _check(lib().pt_get_plan(self._h, C.byref(p)), "pt_get_plan")
+        return p.as_dict()
+
+    def render_seconds(self) -> float:
+        """Wall seconds of the last render call, entry to the device finishing its last batch; < 0 while it runs."""
+        return float(lib().pt_render_seconds(self._h))
+
+    def wait_for(self, timeout_ms: int) -> bool:
+        return bool(_check(lib().pt_wait_for(self._h, int(timeout_ms)), "pt_wait_for"))
 
     def poll(self):
         s, r = C.c_uint64(), C.c_uint64()
@@ -474,6 +524,15 @@ class MultiRenderer:
 
     def render_async(self, spp_begin, spp_end):
         _check(lib().pt_multi_render_async(self._h, spp_begin, spp_end), "pt_multi_render_async")
+
+    def reserve(self, samples: int):
+        _check(lib().pt_multi_reserve(self._h, int(samples)), "pt_multi_reserve")
+
+    def render_seconds(self) -> float:
+        return float(lib().pt_multi_render_seconds(self._h))
+
+    def wait_for(self, timeout_ms: int) -> bool:
+        return bool(_check(lib().pt_multi_wait_for(self._h, int(timeout_ms)), "pt_multi_wait_for"))
 
     def wait(self):
         _check(lib().pt_multi_wait(self._h), "pt_multi_wait")

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -93,6 +96,17 @@ struct pt_ctx {
     int seg_cap = 4096;
     int n_seg_max = 0;
     std::vector<void *> allocs;
+    std::vector<void *> stream_allocs;   // the P-dependent wavefront streams of all lanes (size_streams: freed and re-made when they grow)
+    // the launch plan (include/pathtrace_hip.h, ABI v6)
+    bool auto_size = false;          // max_paths_in_flight = 0: the library sizes the streams from the render calls and the free HBM
+    pt_plan plan{};
+    // wall time of the last render call: entry -> the host function behind its last batch (pt_render_seconds, pt_wait_for)
+    struct Clock {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::chrono::steady_clock::time_point t_begin, t_end;
+        uint64_t issued = 0, landed = 0;   // render calls enqueued / whose last batch has finished
+    } *clock = nullptr;                     // on the heap and never freed before the streams are idle (the callback holds it)
     hipStream_t own_stream = nullptr, stream = nullptr;   // lane 0's stream (stream may be caller-owned)
     hipEvent_t done_ev = nullptr;
     Lane lanes[PT_MAX_LANES];
@@ -707,52 +721,53 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
     return 0;
 }
 
-static int alloc_streams(pt_ctx *c)
+// ---- the launch plan (include/pathtrace_hip.h, ABI v6; measured in DESIGN.md 6) -----------------------------------
+// A call of `npix` pixels x `total_spp` samples with `cap` path slots per batch: as few EQUAL batches as the slots allow,
+// at least two (one batch's thin late bounces overlap nothing: a rank of N = 8 at K = 20 takes 18.6 ms in one batch, 17.6
+// in two, 18.2 in three), a multiple of the lanes beyond the lanes (the last round of batches is a full one: N = 1,
+// K = 20: 4 batches 133.2 ms, 6 batches 129.5).  Returns samples per batch; *n_batches = how many.
+static int plan_batches(int64_t npix, int total_spp, int64_t cap, int lanes, int *n_batches)
 {
-    int64_t want = c->cfg.max_paths_in_flight > 0 ? c->cfg.max_paths_in_flight : (int64_t)8 << 20;
-    want = std::max<int64_t>(want, 64);
-    // a path slot travels as an int32 whose bit 31 is the `pending` flag (k_shade / k_connect), segment counts and pixel
-    // counts are int32: refuse what would overflow them instead of corrupting slot ids
-    if (want > ((int64_t)1 << 30)) {
-        set_err("pt_create: max_paths_in_flight = %lld exceeds 2^30 path slots per batch", (long long)want);
-        return -1;
-    }
+    const int64_t spp_cap = std::max<int64_t>(1, cap / std::max<int64_t>(npix, 1));
+    int64_t batches = std::max<int64_t>(2, (total_spp + spp_cap - 1) / spp_cap);
+    if (batches > lanes) batches = (batches + lanes - 1) / lanes * lanes;
+    const int64_t want = (total_spp + batches - 1) / batches;   // equal batches (the last may be a few samples short)
+    const int spp = (int)std::max<int64_t>(1, std::min<int64_t>(spp_cap, want));
+    if (n_batches) *n_batches = (total_spp + spp - 1) / spp;
+    return spp;
+}
+extern "C" int32_t pt_plan_batches(int64_t pixels, int32_t samples, int64_t path_slots, int32_t lanes, int32_t *batches)
+{
+    int nb = 0;
+    const int spp = plan_batches(std::max<int64_t>(pixels, 1), std::max(samples, 1), std::max<int64_t>(path_slots, 1), std::max(lanes, 1), &nb);
+    if (batches) *batches = nb;
+    return spp;
+}
+static size_t slot_bytes(const pt_ctx *c) { return 192 + 24 * (size_t)std::max(c->cfg.light_samples, 1); }   // pt_device.h DQueue x 2, DShadowQueue, hit, radiance, pending
+
+// What is shared by the lanes or does not depend on the number of path slots: framebuffer, counters, the lanes' HIP
+// streams and events, the live-count words, the general sweep's global stack.
+static int alloc_fixed(pt_ctx *c)
+{
     if ((int64_t)c->cfg.width * c->cfg.height > ((int64_t)1 << 30)) {
         set_err("pt_create: film of %d x %d pixels exceeds 2^30", c->cfg.width, c->cfg.height);
         return -1;
     }
     c->seg_cap = 4096;   // measured on cornell_box 1080p: 1024 -2.4 %, 2048 -1.4 %, 4096 best, 8192 / 16384 -0.3 %
-    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) c->seg_cap = v; }
-    c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
-    c->P = (int64_t)c->n_seg_max * c->seg_cap;
-    c->n_seg_max += 2;
-    c->P_phys = c->P + 2 * (int64_t)(c->seg_cap + 256);
-    const size_t P = (size_t)c->P_phys;
-    const size_t L = (size_t)std::max(c->cfg.light_samples, 1);
-    // framebuffer and counters are shared by the lanes
     if (dev_alloc(c, &c->fb_own, (size_t)c->cfg.width * c->cfg.height)) return -1;
     DCounters *ctr = nullptr;
     if (dev_alloc(c, &ctr, PT_COUNTER_BANKS)) return -1;
     HIP_TRY(hipMemset(c->fb_own, 0, sizeof(float4) * (size_t)c->cfg.width * c->cfg.height));
     HIP_TRY(hipMemset(ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS));
-    // every lane owns a full set of stream buffers (P slots, 288 B each at light_samples = 4).  Measured on cornell_box
-    // 1080p (round 2): 1 lane 23.9, 2 lanes 28.9, 3 lanes 29.3, 4 lanes 27.9 Grays/s -- one lane leaves the thin late
-    // bounces exposed, with three the chip always has a wide kernel to run
+    // every lane owns a full set of stream buffers.  Measured on cornell_box 1080p (round 2): 1 lane 23.9, 2 lanes 28.9,
+    // 3 lanes 29.3, 4 lanes 27.9 Grays/s -- one lane leaves the thin late bounces exposed, with three the chip always has a
+    // wide kernel to run
     const char *env = getenv("PATHTRACE_HIP_LANES");
     c->n_lanes = env ? std::max(1, std::min(PT_MAX_LANES, atoi(env))) : 3;
     c->n_lanes_alloc = c->n_lanes;
     for (int l = 0; l < c->n_lanes; l++) {
         Lane &ln = c->lanes[l];
         DStreams &st = ln.st;
-        for (int i = 0; i < 2; i++) {
-            if (dev_alloc(c, &st.q[i].r0, P) || dev_alloc(c, &st.q[i].r1, P) || dev_alloc(c, &st.q[i].s0, P) ||
-                dev_alloc(c, &st.q[i].s1, P) || dev_alloc(c, &st.q[i].count, (size_t)c->n_seg_max))
-                return -1;
-        }
-        if (dev_alloc(c, &st.sq.p0, P) || dev_alloc(c, &st.sq.key, P) || dev_alloc(c, &st.sq.d, P * L) ||
-            dev_alloc(c, &st.sq.e, P * L) || dev_alloc(c, &st.sq.count, (size_t)c->n_seg_max))
-            return -1;
-        if (dev_alloc(c, &st.hit, P) || dev_alloc(c, &st.radiance, P) || dev_alloc(c, &st.pending, P)) return -1;
         if (dev_alloc(c, &st.qmax, (size_t)launch_qmax_words())) return -1;
         st.gstack = nullptr;
         st.gstack_stride = 0;
@@ -769,6 +784,116 @@ static int alloc_streams(pt_ctx *c)
     c->st = c->lanes[0].st;
     HIP_TRY(hipHostMalloc((void **)&c->host_ctr, sizeof(DCounters) * PT_COUNTER_BANKS));
     memset(c->host_ctr, 0, sizeof(DCounters) * PT_COUNTER_BANKS);
+    return 0;
+}
+
+template <typename T>
+static int stream_alloc(pt_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    c->stream_allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+// The wavefront streams of every lane for `want` path slots per batch.  Called by pt_create (an explicit
+// max_paths_in_flight), by pt_reserve and by the first render call of an auto-sized context -- and again when a later call's
+// plan wants more slots than the context owns: every lane goes idle, the old streams are freed, the new ones allocated.
+static int size_streams(pt_ctx *c, int64_t want)
+{
+    want = std::max<int64_t>(want, 64);
+    // a path slot travels as an int32 whose bit 31 is the `pending` flag (k_shade / k_connect), segment counts and pixel
+    // counts are int32: refuse what would overflow them instead of corrupting slot ids
+    if (want > ((int64_t)1 << 30)) {
+        set_err("pt_create: max_paths_in_flight = %lld exceeds 2^30 path slots per batch", (long long)want);
+        return -1;
+    }
+    if (!c->stream_allocs.empty()) {
+        for (int l = 0; l < c->n_lanes_alloc; l++) HIP_TRY(hipStreamSynchronize(c->lanes[l].stream));
+        for (void *p : c->stream_allocs) (void)hipFree(p);
+        c->stream_allocs.clear();
+        c->have_last = false;
+        c->plan.grown++;
+    }
+    int seg = c->seg_cap;
+    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) seg = v; }
+    c->seg_cap = seg;
+    c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
+    c->P = (int64_t)c->n_seg_max * c->seg_cap;
+    c->n_seg_max += 2;
+    c->P_phys = c->P + 2 * (int64_t)(c->seg_cap + 256);
+    const size_t P = (size_t)c->P_phys;
+    const size_t L = (size_t)std::max(c->cfg.light_samples, 1);
+    size_t hfree = 0, htotal = 0;
+    if (hipMemGetInfo(&hfree, &htotal) == hipSuccess) c->plan.hbm_free_bytes = (int64_t)hfree;
+    auto salloc = [&](auto **p, size_t n) -> int { return stream_alloc(c, p, n); };
+    for (int l = 0; l < c->n_lanes_alloc; l++) {
+        DStreams &st = c->lanes[l].st;
+        for (int i = 0; i < 2; i++) {
+            if (salloc(&st.q[i].r0, P) || salloc(&st.q[i].r1, P) || salloc(&st.q[i].s0, P) || salloc(&st.q[i].s1, P) ||
+                salloc(&st.q[i].count, (size_t)c->n_seg_max))
+                return -1;
+        }
+        if (salloc(&st.sq.p0, P) || salloc(&st.sq.key, P) || salloc(&st.sq.d, P * L) || salloc(&st.sq.e, P * L) ||
+            salloc(&st.sq.count, (size_t)c->n_seg_max))
+            return -1;
+        if (salloc(&st.hit, P) || salloc(&st.radiance, P) || salloc(&st.pending, P)) return -1;
+    }
+    {   // the caller's framebuffer (pt_set_device_framebuffer) stays the one the batches add to
+        float4 *fb = c->st.fb;
+        c->st = c->lanes[0].st;
+        c->st.fb = fb;
+    }
+    c->plan.path_slots = c->P;
+    c->plan.stream_bytes = (int64_t)(P * slot_bytes(c) * (size_t)c->n_lanes_alloc);
+    return 0;
+}
+
+// Path slots the plan wants for calls of `pixels` x `samples` on an auto-sized context: pixels x its samples per batch, within
+// PT_PLAN_MAX_PATHS and PT_PLAN_HBM_FRACTION of the memory that is free now plus what the context's streams already hold.
+static int64_t plan_slots(pt_ctx *c, int64_t pixels, int samples)
+{
+    size_t hfree = 0, htotal = 0;
+    int64_t cap = PT_PLAN_MAX_PATHS;
+    if (const char *e = getenv("PATHTRACE_HIP_PLAN_MAX_PATHS")) { const long long v = atoll(e); if (v >= 64) cap = v; }   // measurement knob
+    if (hipMemGetInfo(&hfree, &htotal) == hipSuccess) {
+        const double avail = ((double)hfree + (double)c->plan.stream_bytes) * PT_PLAN_HBM_FRACTION;
+        const int64_t by_mem = (int64_t)(avail / ((double)slot_bytes(c) * c->n_lanes_alloc)) - 2 * (int64_t)(c->seg_cap + 256);
+        cap = std::max<int64_t>(64, std::min(cap, by_mem));
+    }
+    const int spp = plan_batches(pixels, samples, cap, c->n_lanes, nullptr);
+    return std::min<int64_t>(cap, std::max<int64_t>(pixels, 1) * spp);
+}
+
+// Before a render call of `pixels` x `samples`: an auto-sized context gets (or grows to) the slots the plan wants.
+static int ensure_streams(pt_ctx *c, int64_t pixels, int samples)
+{
+    if (!c->auto_size) return 0;
+    const int64_t want = plan_slots(c, pixels, samples);
+    if (c->stream_allocs.empty() || want > c->P) return size_streams(c, want);
+    return 0;
+}
+
+extern "C" int pt_reserve(pt_ctx *c, int64_t pixels, int32_t samples)
+{
+    if (!c || pixels < 1 || samples < 1) { set_err("pt_reserve: bad argument"); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_streams(c, pixels, samples)) return -1;
+    int nb = 0;
+    c->plan.pixels = pixels; c->plan.samples = samples;
+    c->plan.spp_per_batch = plan_batches(pixels, samples, c->P, c->n_lanes, &nb);
+    c->plan.batches = nb;
+    c->plan.paths_per_batch = pixels * c->plan.spp_per_batch;
+    return 0;
+}
+
+extern "C" int pt_get_plan(pt_ctx *c, pt_plan *out)
+{
+    if (!c || !out) { set_err("pt_get_plan: null argument"); return -1; }
+    *out = c->plan;
+    out->lanes = c->n_lanes;
+    out->auto_sized = c->auto_size ? 1 : 0;
     return 0;
 }
 
@@ -796,7 +921,11 @@ extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config
     c->stream = c->own_stream;
     if (hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming) != hipSuccess) { set_err("pt_create: event"); return fail(); }
     if (build_scene(c, scene)) return fail();
-    if (alloc_streams(c)) return fail();
+    c->clock = new pt_ctx::Clock();
+    if (alloc_fixed(c)) return fail();
+    // max_paths_in_flight = 0: the streams are sized by the launch plan from the first render call / pt_reserve (ABI v6)
+    c->auto_size = c->cfg.max_paths_in_flight <= 0;
+    if (!c->auto_size && size_streams(c, c->cfg.max_paths_in_flight)) return fail();
     {   // the per-scene build of the sweep: PATHTRACE_HIP_SPEC = async (default: built on a thread of its own, used when ready),
         // sync (built before pt_create returns), off.  Scenes without a fast program keep the generic kernels.
         const char *mode = getenv("PATHTRACE_HIP_SPEC");
@@ -824,7 +953,9 @@ extern "C" void pt_destroy(pt_ctx *c)
         if (l > 0 && c->lanes[l].stream) (void)hipStreamDestroy(c->lanes[l].stream);
     }
     spec_destroy(c->spec);
+    for (void *p : c->stream_allocs) (void)hipFree(p);
     for (void *p : c->allocs) (void)hipFree(p);
+    delete c->clock;   // every lane is idle (synchronised above): no host function of a render call is pending
     if (c->host_ctr) (void)hipHostFree(c->host_ctr);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto &m : c->marks) (void)hipEventDestroy(m.ev);
@@ -988,9 +1119,19 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
                 (long long)npix, g1 - g0, tile_off, (long long)c->P, c->h_tiles.size());
         return -1;
     }
-    const int ns_fit = (int)std::max<int64_t>(1, c->P / npix);
+    // the launch plan (plan_batches): equal batches, as few as the slots allow, at least two, a multiple of the lanes
+    // (PATHTRACE_HIP_PLAN=caller, a measurement knob: the caller's calls ARE the batches, cut only where the slots force it --
+    // the rule up to ABI v5 -- so that tools/plan_probe.py can time plans other than the library's)
+    static const bool caller_plan = getenv("PATHTRACE_HIP_PLAN") && !strcmp(getenv("PATHTRACE_HIP_PLAN"), "caller");
+    int n_batches = 0;
+    int ns_plan = plan_batches(npix, spp_end - spp_begin, c->P, c->n_lanes, &n_batches);
+    if (caller_plan) { ns_plan = (int)std::max<int64_t>(1, c->P / npix); n_batches = (spp_end - spp_begin + ns_plan - 1) / ns_plan; }
+    if (g0 == 0) {
+        c->plan.pixels = npix; c->plan.samples = spp_end - spp_begin; c->plan.spp_per_batch = ns_plan;
+        c->plan.batches = n_batches; c->plan.paths_per_batch = npix * ns_plan;
+    }
     for (int s = spp_begin; s < spp_end;) {
-        const int ns = std::min(ns_fit, spp_end - s);
+        const int ns = std::min(ns_plan, spp_end - s);
         DBatch b{};
         b.x0 = bands[g0].x0; b.y0 = bands[g0].y0; b.w = bands[g0].w;
         b.n_tiles = (int)(g1 - g0);
@@ -1028,6 +1169,12 @@ static int render_tiles(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_
     if (!c || !rects || n_rects < 1) { set_err("pt_render_tiles_async: bad argument"); return -1; }
     if (spp_begin < 0 || spp_end <= spp_begin) { set_err("pt_render_tiles_async: bad sample range [%d,%d)", spp_begin, spp_end); return -1; }
     HIP_TRY(hipSetDevice(c->device));
+    const auto t_entry = std::chrono::steady_clock::now();
+    {   // an auto-sized context gets / grows its streams for this call (include/pathtrace_hip.h "the launch plan")
+        int64_t total = 0;
+        for (int r = 0; r < n_rects; r++) total += (int64_t)std::max(rects[4 * r + 2] - rects[4 * r], 0) * std::max(rects[4 * r + 3] - rects[4 * r + 1], 0);
+        if (ensure_streams(c, std::max<int64_t>(total, 1), spp_end - spp_begin)) return -1;
+    }
     // rects -> bands of at most P pixels each
     std::vector<DTile> bands;
     std::vector<int> band_h;
@@ -1096,7 +1243,47 @@ static int render_tiles(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_
         if (render_group(c, bands, band_h, g.g0, g.g1, g.off, spp_begin, spp_end)) { c->tally = nullptr; return -1; }
     // the last accumulate transitively waited for every earlier accumulate, i.e. for every earlier batch
     HIP_TRY(hipEventRecord(c->done_ev, c->lanes[c->last_lane].stream));
+    {   // the call's clock: a host function behind the last batch stamps the time the device finished (pt_render_seconds, pt_wait_for)
+        {
+            std::lock_guard<std::mutex> g(c->clock->mu);
+            c->clock->t_begin = t_entry;
+            c->clock->issued++;
+        }
+        HIP_TRY(hipLaunchHostFunc(c->lanes[c->last_lane].stream, [](void *p) {
+            pt_ctx::Clock *k = (pt_ctx::Clock *)p;
+            std::lock_guard<std::mutex> g(k->mu);
+            k->t_end = std::chrono::steady_clock::now();
+            k->landed++;
+            k->cv.notify_all();
+        }, c->clock));
+    }
     return 0;
+}
+
+extern "C" double pt_render_seconds(pt_ctx *c)
+{
+    if (!c || !c->clock) return -1.0;
+    std::lock_guard<std::mutex> g(c->clock->mu);
+    if (c->clock->issued == 0 || c->clock->landed != c->clock->issued) return -1.0;
+    return std::chrono::duration<double>(c->clock->t_end - c->clock->t_begin).count();
+}
+
+// pt_multi.cpp: when the last render call of this context landed (false while it is running or before any call)
+bool pt_clock_end(pt_ctx *c, std::chrono::steady_clock::time_point *t_end)
+{
+    if (!c || !c->clock) return false;
+    std::lock_guard<std::mutex> g(c->clock->mu);
+    if (c->clock->issued == 0 || c->clock->landed != c->clock->issued) return false;
+    *t_end = c->clock->t_end;
+    return true;
+}
+
+extern "C" int pt_wait_for(pt_ctx *c, int32_t timeout_ms)
+{
+    if (!c || !c->clock) { set_err("pt_wait_for: null ctx"); return -1; }
+    std::unique_lock<std::mutex> g(c->clock->mu);
+    const bool idle = c->clock->cv.wait_for(g, std::chrono::milliseconds(std::max(timeout_ms, 0)), [&] { return c->clock->landed == c->clock->issued; });
+    return idle ? 1 : 0;
 }
 
 extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t spp_begin, int32_t spp_end)

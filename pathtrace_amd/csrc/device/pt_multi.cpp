@@ -20,17 +20,20 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/pathtrace_hip.h"
 
 void pth_set_error(const std::string &m);
+bool pt_clock_end(pt_ctx *c, std::chrono::steady_clock::time_point *t_end);   // pt_context.cpp
 namespace ptd {
 void launch_add_fb(void *dst_rgba, const void *src_rgba, long long n_pixels, hipStream_t s);
 void launch_pack_tiles(void *packed, const void *fb, const void *rects, const void *pix0, int n, int width, int total, hipStream_t s);
@@ -106,6 +109,8 @@ struct pt_multi {
     std::vector<void *> comms;
     std::vector<hipStream_t> rstreams;         // one per device for the RCCL group
     std::vector<float> host_tmp;
+    std::chrono::steady_clock::time_point t_render;   // entry of the last pt_multi_render_async
+    bool rendered = false;
 };
 
 // longest-processing-time greedy (costliest tile first, ties by spiral index, to the least loaded owner, ties to the
@@ -256,14 +261,83 @@ extern "C" pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config
     return m;
 }
 
+// Every device is driven by a host thread of its own -- the counterpart of Tiled::start_render's worker threads
+// (renderer.h:553-603), with the difference that a worker here only ENQUEUES: sizing its context's streams (the launch plan,
+// pt_context.cpp) and a few hundred kernel launches per device, which one thread would otherwise issue device after device
+// (round 4: ~7 700 launches per device from one thread with the old 8 Mi-path default).  The call returns when every device
+// has its work queued; nothing waits for the devices themselves.
+template <typename F>
+static int on_every_device(pt_multi *m, const char *what, F f)
+{
+    const size_t n = m->ctx.size();
+    std::vector<std::string> err(n);
+    std::vector<int> rc(n, 0);
+    auto work = [&](size_t i) {
+        rc[i] = f(i);
+        if (rc[i]) err[i] = pt_last_error();   // the message is thread-local: carried over to the caller's thread below
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < n; i++) th.emplace_back(work, i);
+    work(0);
+    for (std::thread &t : th) t.join();
+    for (size_t i = 0; i < n; i++)
+        if (rc[i]) { merr("%s: device slot %zu: %s", what, i, err[i].c_str()); return -1; }
+    return 0;
+}
+static int64_t owned_pixels(const pt_multi *m, size_t i)
+{
+    int64_t px = 0;
+    for (size_t k = 0; k + 3 < m->rects[i].size(); k += 4) px += (int64_t)(m->rects[i][k + 2] - m->rects[i][k]) * (m->rects[i][k + 3] - m->rects[i][k + 1]);
+    return px;
+}
+
 extern "C" int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp_end)
 {
     if (!m) { merr("pt_multi_render_async: null"); return -1; }
-    for (size_t i = 0; i < m->ctx.size(); i++) {
+    m->t_render = std::chrono::steady_clock::now();
+    m->rendered = true;
+    return on_every_device(m, "pt_multi_render_async", [&](size_t i) {
         const int n = (int)(m->rects[i].size() / 4);
-        if (n && pt_render_tiles_async(m->ctx[i], n, m->rects[i].data(), spp_begin, spp_end)) return -1;
+        return n ? pt_render_tiles_async(m->ctx[i], n, m->rects[i].data(), spp_begin, spp_end) : 0;
+    });
+}
+
+extern "C" int pt_multi_reserve(pt_multi *m, int32_t samples)
+{
+    if (!m || samples < 1) { merr("pt_multi_reserve: bad argument"); return -1; }
+    return on_every_device(m, "pt_multi_reserve", [&](size_t i) {
+        const int64_t px = owned_pixels(m, i);
+        if (!px) return 0;
+        if (pt_reserve(m->ctx[i], px, samples)) return -1;
+        (void)pt_spec_wait(m->ctx[i]);   // every device on its scene's own kernels before the first timed launch (-1: generic kernels)
+        return 0;
+    });
+}
+
+extern "C" double pt_multi_render_seconds(pt_multi *m)
+{
+    if (!m || !m->rendered) return -1.0;
+    std::chrono::steady_clock::time_point last = m->t_render;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        if (m->rects[i].empty()) continue;
+        std::chrono::steady_clock::time_point t;
+        if (!pt_clock_end(m->ctx[i], &t)) return -1.0;
+        last = std::max(last, t);
     }
-    return 0;
+    return std::chrono::duration<double>(last - m->t_render).count();
+}
+
+extern "C" int pt_multi_wait_for(pt_multi *m, int32_t timeout_ms)
+{
+    if (!m) { merr("pt_multi_wait_for: null"); return -1; }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(std::max(timeout_ms, 0));
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        if (m->rects[i].empty()) continue;
+        const auto left = std::chrono::duration_cast<std::chrono::milliseconds>(deadline - std::chrono::steady_clock::now()).count();
+        const int r = pt_wait_for(m->ctx[i], (int32_t)std::max<long long>(left, 0));
+        if (r <= 0) return r;
+    }
+    return 1;
 }
 
 extern "C" int pt_multi_poll(pt_multi *m, uint64_t *samples_done, uint64_t *rays_done)

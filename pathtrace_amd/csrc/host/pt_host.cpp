@@ -965,11 +965,14 @@ public:
 };
 
 // render_type "hip_wavefront": start_render enqueues the whole image on the GPU(s) and returns; sync_progress polls.
-// Default: ONE context on the current device.  PATHTRACE_HIP_DEVICES="0,1,.." lists the devices that take part (pt_multi:
-// tiles of block_width x block_height in NaiveSpiral order, cost-balanced ownership, one sum into the first device at the
-// end) -- the counterpart of Tiled's config.threads workers over one tile queue (renderer.h:553-603); "all" = every
-// visible device; an ordinal may repeat ("0,0": two contexts on one GPU, the rehearsal of the multi-GPU path on a one-GPU
-// box).  The in-process multi-device form has only been rehearsed on one GPU so far, hence it is opt-in.
+// Which devices: config.json's own worker count, `threads` (config.h:117; Tiled::start_render spawns that many workers over
+// one tile queue, renderer.h:553-603) -- threads > 1 = that many GPUs, capped by the devices present, through pt_multi (tiles
+// of block_width x block_height in NaiveSpiral order, cost-balanced ownership, one exchange of the owned tiles at the end);
+// threads <= 1, or one device = ONE context on the current device.  PATHTRACE_HIP_DEVICES="0,1,.." overrides the choice
+// ("all" = every visible device; an ordinal may repeat -- "0,0": two contexts on one GPU, the rehearsal of the multi-GPU path
+// on a one-GPU box).  The constructor does what is set-up in the reference too (Renderer::Renderer allocates the
+// framebuffer, renderer.h:121-133): it sizes the wavefront streams for the job by the library's launch plan (pt_reserve) and
+// waits for the per-scene build of the traversal kernels, so that start_render -> finalize times rendering alone.
 class HipWavefront : public Renderer {
 public:
     HipWavefront(const pth_config &cfg, const pt_scene_desc *scene)
@@ -978,7 +981,8 @@ public:
         pt_config pc{};
         pc.width = cfg.width; pc.height = cfg.height; pc.max_bounces = cfg.max_bounces; pc.light_samples = cfg.light_samples;
         pc.russian_roulette = cfg.russian_roulette; pc.only_direct_illumination = cfg.only_direct_illumination;
-        pc.normal_offset = cfg.normal_offset; pc.seed = 0; pc.device = -1; pc.max_paths_in_flight = 0;
+        pc.normal_offset = cfg.normal_offset; pc.seed = 0; pc.device = -1;
+        pc.max_paths_in_flight = 0;   // the library's launch plan sizes the context (include/pathtrace_hip.h, ABI v6)
         std::vector<int32_t> devices;
         const char *e = getenv("PATHTRACE_HIP_DEVICES");
         if (e && !strcmp(e, "all")) {
@@ -991,14 +995,20 @@ public:
                 devices.push_back((int32_t)v);
                 p = (*end == ',') ? end + 1 : end;
             }
+        } else if (cfg.threads > 1) {
+            const int n = std::min<int>((int)cfg.threads, pt_device_count());
+            for (int d = 0; d < n && n > 1; d++) devices.push_back(d);
         }
         if (devices.size() > 1) {
             multi = pt_multi_create(scene, &pc, (int32_t)devices.size(), devices.data(), std::max(cfg.block_width, 1), std::max(cfg.block_height, 1));
             if (!multi) throw JsonError(std::string("pt_multi_create: ") + pt_last_error());
+            if (pt_multi_reserve(multi, std::max(cfg.samples, 1))) throw JsonError(std::string("pt_multi_reserve: ") + pt_last_error());
         } else {
             if (devices.size() == 1) pc.device = devices[0];
             ctx = pt_create(scene, &pc);
             if (!ctx) throw JsonError(std::string("pt_create: ") + pt_last_error());
+            if (pt_reserve(ctx, (int64_t)cfg.width * cfg.height, std::max(cfg.samples, 1))) throw JsonError(std::string("pt_reserve: ") + pt_last_error());
+            (void)pt_spec_wait(ctx);   // -1: no per-scene build for this scene / machine, the generic kernels render
         }
         framebuffer.assign((size_t)cfg.width * cfg.height * 3, 0.0f);
     }
@@ -1035,14 +1045,22 @@ public:
         completed = r == 1;
     }
     bool is_done() override { return completed; }
+    // the sleep of main.cpp:162, ending early when the device has finished
+    void idle(int ms) { if (multi) (void)pt_multi_wait_for(multi, ms); else (void)pt_wait_for(ctx, ms); }
     void finalize() override
     {
         if (multi ? pt_multi_wait(multi) : pt_wait(ctx)) throw JsonError(pt_last_error());
-        double dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - render_start).count();
+        // "time taken to compute" (renderer.h:698-700) is finalize's clock minus start_render's in the reference, i.e. it
+        // includes up to one sleep of the caller's polling loop; the library stamps the moment the device finished
+        // (pt_render_seconds), which is what this prints -- the wall figure of this process stands beside it
+        const double wall = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - render_start).count();
+        double dt = multi ? pt_multi_render_seconds(multi) : pt_render_seconds(ctx);
+        if (!(dt > 0)) dt = wall;
         pt_counters c{};
         if (multi ? pt_multi_get_counters(multi, &c) : pt_get_counters(ctx, &c)) throw JsonError(pt_last_error());
         if (multi ? pt_multi_read_framebuffer(multi, framebuffer.data()) : pt_read_framebuffer(ctx, framebuffer.data())) throw JsonError(pt_last_error());
         printf("\ntime taken to compute %g\n", dt);
+        printf("(start_render to finalize on this process's clock, polling included: %g)\n", wall);
         if (multi) {
             printf("rendered on %d devices\n", pt_multi_device_count(multi));
             for (int d = 0; d < pt_multi_device_count(multi); d++) {   // the reference prints one bounce count per worker thread
@@ -1054,7 +1072,13 @@ public:
         }
         printf("computed %llu camera rays in %gs, at %g rays per second\n", (unsigned long long)c.camera_samples, dt, c.camera_samples / dt);
         printf("computed %llu rays, at %g rays per second\n", (unsigned long long)c.rays, c.rays / dt);
-        if (ctx) {   // who compiled the traversal kernels this render ran (pt_spec_info): a foreign compiler is correct and slower
+        printf("traced %llu rays, at %g rays per second\n", (unsigned long long)c.rays_traced, c.rays_traced / dt);
+        if (ctx) {
+            pt_plan pl{};
+            if (!pt_get_plan(ctx, &pl))
+                printf("launch plan: %d batches of %d spp (%lld paths each) on %d lanes, %lld path slots, %.1f GB of streams%s\n", pl.batches, pl.spp_per_batch,
+                       (long long)pl.paths_per_batch, pl.lanes, (long long)pl.path_slots, pl.stream_bytes / 1e9, pl.auto_sized ? " (sized by the library)" : "");
+            // who compiled the traversal kernels this render ran (pt_spec_info): a foreign compiler is correct and slower
             char info[1024];
             const int n = pt_spec_info(ctx, info, sizeof info);
             if (n > 0 && n < (int)sizeof info) printf("per-scene kernels: %s\n", info);
@@ -1092,7 +1116,7 @@ extern "C" int pth_main(const char *workdir)
             r.start_render(t2);
             while (!r.is_done()) {
                 r.sync_progress();
-                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                if (!r.is_done()) r.idle(50);   // main.cpp:162 sleeps 0.5 s; this wait ends when the device does
             }
             printf(" done\n");
             r.finalize();

@@ -33,7 +33,13 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank():
     for k in ("spp_total", "camera_samples", "rays", "framebuffer_sum"):
         assert one["config"][k] == two["config"][k], (k, one["config"][k], two["config"][k])
     for d in (one, two):
-        assert d["roofline"]["bound"] in ("hbm", "valu-issue") and d["roofline"]["bound_basis"] and d["value"] > 0 and d["steps"] == 4
+        assert d["roofline"]["bound"] in ("hbm", "valu-issue", "latency") and d["roofline"]["bound_basis"] and d["value"] > 0 and d["steps"] == 4
+        if d["roofline"]["bound"] == "latency":   # named from the same-build wait-state counters: a wave parked on s_waitcnt more than it issues and executes
+            w = d["roofline"]["wave_life"]
+            assert d["roofline"]["parked"] == w["parked"] > w["stalled_at_issue"] + w["executing"]
+        # the launch plan is the library's: bench.py passes no size and makes one render call per pass
+        lp = d["config"]["launch_plan"]
+        assert lp["auto_sized"] == 1 and lp["batches"] >= 2 and "libpathtrace_hip.so" in lp["decided_by"]
         # the fractions the label is chosen from, side by side: the contract's model bytes, this implementation's record bytes
         assert 0 < d["roofline"]["hbm_frac_stream"] <= d["roofline"]["hbm_frac_model"] * 1.5 and d["roofline"]["frac"] == d["roofline"]["hbm_frac_model"]
         assert d["config"]["module"]["sweep"].startswith("per-scene build") and d["config"]["module"]["own_compiler"] is True, d["config"]["module"]
@@ -50,6 +56,10 @@ def test_bench_self_launches_two_ranks_and_matches_one_rank():
     for e in px["by_n"]:
         assert e["rays_all_ranks"] == one["config"]["rays"] and min(e["batches_per_rank"]) >= 2 and e["predicted_efficiency"] > 0
     assert two["scaling_proxy"] is None
+    # the plugin surface (pth_main in a child process, config.json in) rendered the same frame and samples with the library's plan
+    pm = one["plugin_path"]["pth_main"]
+    assert pm["rc"] == 0 and pm["rays_traced"] == one["config"]["rays_traced"] and pm["launch_plan"]["batches"] == one["config"]["launch_plan"]["batches"]
+    assert pm["value"] > 0 and two["plugin_path"] is None
 
 
 def test_bench_four_rank_rehearsal_of_the_launch_path():

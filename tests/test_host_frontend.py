@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(pt.EXPORTS), declared ^ set(pt.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pt_abi_version() == 5
+    assert L.pt_abi_version() == 6
 
 
 @pytest.mark.parametrize("scene", ALL_SCENES)

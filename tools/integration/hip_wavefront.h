@@ -9,6 +9,8 @@
 //   HipFlatScene  walks the reference's object graph into the flat POD scene of include/pathtrace_hip.h;
 //   HipWavefront  forwards start_render / sync_progress / is_done / finalize to the C ABI.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -189,6 +191,12 @@ struct HipFlatScene {
     }
 };
 
+// Which GPUs render: the reference's own worker count, config.threads (config.h:117; Tiled::start_render spawns that many
+// worker threads over one spiral tile queue, renderer.h:553-603).  threads > 1 = that many devices, capped by the devices
+// present, through pt_multi_* (one context per device, tiles of block_width x block_height in NaiveSpiral order owned by
+// cost-balanced devices, every device driven by a host thread of its own, one exchange of the owned tiles at the end);
+// threads <= 1 or a one-GPU machine = one context.  PATHTRACE_HIP_DEVICES="0,1,.." overrides the list ("all" = every visible
+// device; an ordinal may repeat: "0,0" rehearses the multi-device path on a one-GPU box).
 class HipWavefront : public Renderer
 {
 public:
@@ -200,9 +208,36 @@ public:
         pc.width = film.width; pc.height = film.height;
         pc.max_bounces = config.max_bounces; pc.light_samples = config.light_samples;
         pc.russian_roulette = config.russian_roulette; pc.only_direct_illumination = config.only_direct_illumination;
-        pc.normal_offset = config.normal_offset; pc.seed = 0; pc.device = -1; pc.max_paths_in_flight = 0;
-        ctx = pt_create(&flat.desc, &pc);
-        ASSERT(ctx != nullptr, pt_last_error());                              // the reference's error style (types.h:5-14)
+        pc.normal_offset = config.normal_offset; pc.seed = 0; pc.device = -1;
+        pc.max_paths_in_flight = 0;                                           // the library's launch plan sizes the streams (ABI v6)
+        std::vector<int32_t> devices;
+        if (const char *e = getenv("PATHTRACE_HIP_DEVICES")) {
+            if (!strcmp(e, "all")) for (int d = 0; d < pt_device_count(); d++) devices.push_back(d);
+            else for (const char *p = e; *p;) {
+                char *end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int32_t)v);
+                p = (*end == ',') ? end + 1 : end;
+            }
+        } else if (config.threads > 1) {
+            const int n = std::min<int>((int)config.threads, pt_device_count());
+            for (int d = 0; d < n && n > 1; d++) devices.push_back(d);
+        }
+        // set-up, like Renderer::Renderer's framebuffer allocation (renderer.h:121-133): the wavefront streams for this job
+        // (pt_reserve: the launch plan from film x samples and the free HBM) and the per-scene build of the traversal
+        // kernels, so that start_render -> finalize times rendering alone
+        if (devices.size() > 1) {
+            multi = pt_multi_create(&flat.desc, &pc, (int32_t)devices.size(), devices.data(), std::max(config.block_width, 1), std::max(config.block_height, 1));
+            ASSERT(multi != nullptr, pt_last_error());
+            ASSERT(pt_multi_reserve(multi, std::max(config.samples, 1)) == 0, pt_last_error());
+        } else {
+            if (devices.size() == 1) pc.device = devices[0];
+            ctx = pt_create(&flat.desc, &pc);
+            ASSERT(ctx != nullptr, pt_last_error());                          // the reference's error style (types.h:5-14)
+            ASSERT(pt_reserve(ctx, (int64_t)film.width * film.height, std::max(config.samples, 1)) == 0, pt_last_error());
+            (void)pt_spec_wait(ctx);                                          // -1: the generic kernels render
+        }
         staging.resize((size_t)film.width * film.height * 3);
         completed = false;
     }
@@ -211,7 +246,8 @@ public:
     {
         render_start_time = std::chrono::high_resolution_clock::now();
         // whole film, all samples: enqueued asynchronously, returns at once (replaces the thread spawn renderer.h:595)
-        ASSERT(pt_render_async(ctx, 0, 0, film.width, film.height, 0, config.samples) == 0, pt_last_error());
+        const int rc = multi ? pt_multi_render_async(multi, 0, config.samples) : pt_render_async(ctx, 0, 0, film.width, film.height, 0, config.samples);
+        ASSERT(rc == 0, pt_last_error());
     }
     void next_pixel_and_ray(int, ray &, int, int) {}
     void to_framebuffer()
@@ -225,12 +261,13 @@ public:
     void sync_progress()
     {
         uint64_t samples = 0, rays = 0;
-        const int done = pt_poll(ctx, &samples, &rays);                        // replaces summing samples_done[] (renderer.h:607-612)
+        const int done = multi ? pt_multi_poll(multi, &samples, &rays) : pt_poll(ctx, &samples, &rays);   // replaces summing samples_done[] (renderer.h:607-612)
         ASSERT(done >= 0, pt_last_error());
         print_out_progress((long)samples, (long)config.samples * film.total_pixels - (long)samples, render_start_time);
         if (!done) {                                                          // preview from the LIVE framebuffer (renderer.h:614-618)
             uint64_t acc = 0;
-            ASSERT(pt_snapshot_framebuffer(ctx, staging.data(), &acc) == 0, pt_last_error());
+            const int rc = multi ? pt_multi_snapshot_framebuffer(multi, staging.data(), &acc) : pt_snapshot_framebuffer(ctx, staging.data(), &acc);
+            ASSERT(rc == 0, pt_last_error());
             to_framebuffer();
             float avg, mx, tot;
             const int div = 1 + (int)(acc / ((uint64_t)film.width * film.height));
@@ -243,13 +280,31 @@ public:
     void compute(int) {}                                                      // no CPU worker threads
     void finalize()
     {
-        ASSERT(pt_wait(ctx) == 0, pt_last_error());
-        ASSERT(pt_read_framebuffer(ctx, staging.data()) == 0, pt_last_error());
+        ASSERT((multi ? pt_multi_wait(multi) : pt_wait(ctx)) == 0, pt_last_error());
+        // renderer.h:696-706.  The reference's elapsed time is finalize's clock minus start_render's, which includes up to one
+        // 0.5 s sleep of main.cpp:158-163's loop; the library stamps the moment the device finished its last batch
+        // (pt_render_seconds) and that is what the rates below use; the process's own wall figure is printed beside it.
+        const std::chrono::duration<double> wall = std::chrono::high_resolution_clock::now() - render_start_time;
+        double dt = multi ? pt_multi_render_seconds(multi) : pt_render_seconds(ctx);
+        if (!(dt > 0)) dt = wall.count();
+        ASSERT((multi ? pt_multi_read_framebuffer(multi, staging.data()) : pt_read_framebuffer(ctx, staging.data())) == 0, pt_last_error());
         to_framebuffer();
         pt_counters c;
-        pt_get_counters(ctx, &c);                                             // c.rays = total_bounces of renderer.h:696-706
+        ASSERT((multi ? pt_multi_get_counters(multi, &c) : pt_get_counters(ctx, &c)) == 0, pt_last_error());   // c.rays = total_bounces of renderer.h:696-706
         rays_traced = c.rays;
-        {   // ABI v5: who compiled the traversal kernels this render ran -- a foreign compiler (a host process that carries
+        const int workers = multi ? pt_multi_device_count(multi) : 1;
+        std::cout << "time taken to compute " << dt << std::endl;
+        std::cout << "(start_render to finalize on this process's clock, polling included: " << wall.count() << ")" << std::endl;
+        const float rate1 = film.total_pixels * config.samples / dt, rate2 = c.rays / dt;
+        std::cout << "computed " << film.total_pixels * config.samples << " camera rays in " << dt << "s, at " << rate1 << " rays per second, or " << rate1 / workers << "per device" << std::endl;
+        std::cout << "computed " << c.rays << " rays, at " << rate2 << " rays per second, or " << rate2 / workers << " per device" << std::endl;
+        std::cout << "traced " << c.rays_traced << " rays, at " << (float)(c.rays_traced / dt) << " rays per second" << std::endl;
+        if (ctx) {
+            pt_plan pl;
+            if (pt_get_plan(ctx, &pl) == 0)
+                std::cout << "launch plan: " << pl.batches << " batches of " << pl.spp_per_batch << " spp on " << pl.lanes << " lanes, " << pl.path_slots
+                          << " path slots, " << pl.stream_bytes / 1e9 << " GB of streams" << std::endl;
+            // ABI v5: who compiled the traversal kernels this render ran -- a foreign compiler (a host process that carries
             // another ROCm under the same sonames) builds correct, measurably slower kernels: say so next to the statistics
             char info[1024];
             const int n = pt_spec_info(ctx, info, sizeof info);
@@ -258,11 +313,16 @@ public:
         float max_luminance, avg_luminance, total_luminance;                  // unchanged film output, renderer.h:719-727
         calculate_luminance(framebuffer, film.width, film.height, config.samples, film.width * film.height, max_luminance,
                             total_luminance, avg_luminance);
+        std::cout << "avg lum " << avg_luminance << std::endl;
+        std::cout << "max lum " << max_luminance << std::endl;
         output_to_file(output, framebuffer, film.width, film.height, config.samples, max_luminance, film.exposure, film.gamma);
         pt_destroy(ctx);
+        pt_multi_destroy(multi);
         ctx = nullptr;
+        multi = nullptr;
     }
     pt_ctx *ctx = nullptr;
+    pt_multi *multi = nullptr;
     HipFlatScene flat;
     std::vector<float> staging;
     uint64_t rays_traced = 0;

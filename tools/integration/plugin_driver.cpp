@@ -5,7 +5,8 @@
 // pth_scene_from_file's.
 //
 //   plugin_driver params.txt flatten W H out.txt      canonical text dump of the plugin's pt_scene_desc
-//   plugin_driver params.txt render  <cfg...> out.f32 the whole Renderer protocol through HipWavefront (needs a GPU)
+//   plugin_driver params.txt render  <cfg...> out.f32 [threads] the whole Renderer protocol through HipWavefront (needs a GPU);
+//                                                      threads = config.threads = GPUs that take part (default 1)
 //
 // The scene comes from oracle/ref_build.h (the reference's constructors driven by oracle/scene_params.py's text), because
 // the reference's own scene_parser.h includes the un-vendored lodepng header and does not compile here.
@@ -25,6 +26,8 @@
 #include "integrator.h"
 #include "renderer.h"
 #include "config.h"
+
+#include <thread>
 
 #include "ref_build.h"
 #include "hip_wavefront.h"
@@ -119,14 +122,17 @@ int main(int argc, char **argv)
         c.block_width = atoi(a[8]); c.block_height = atoi(a[9]);
         c.ppm_output_path = "/dev/null"; c.png_output_path = ""; c.traced_paths_output_path = "/dev/null";
         c.traced_paths_2d_output_path = "/dev/null"; c.scene_path = ""; c.should_trace_paths = false; c.avg_number_of_paths = 100;
-        c.trace_probability = 0.0; c.render_type = TILED; c.integrator_type = INEEPT; c.threads = 1;
+        c.trace_probability = 0.0; c.render_type = TILED; c.integrator_type = INEEPT; c.threads = argc > 14 ? (uint16_t)atoi(argv[14]) : 1;
         camera cam(vec3(b.cam[0], b.cam[1], b.cam[2]), vec3(b.cam[3], b.cam[4], b.cam[5]), vec3(0, 1, 0), b.cam[6],
                    float(c.film.width) / float(c.film.height), b.cam[7], b.cam[8], 0.0, 1.0);
         b.world->config = c;                                                   // main.cpp:139
         Integrator *integrator = new NEEIterative(c.max_bounces, b.world);     // main.cpp:30-55 (only its type selects the kernels)
         Renderer *r = new HipWavefront(integrator, cam, c, b.world, lists);    // main.cpp:57-84 + the new case
         r->start_render(std::chrono::high_resolution_clock::now());           // main.cpp:156-167
-        while (!r->is_done()) r->sync_progress();
+        while (!r->is_done()) {                                               // main.cpp:158-163 (it sleeps 0.5 s; the preview is the same work)
+            r->sync_progress();
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
         r->finalize();
         FILE *f = fopen(a[10], "wb");
         for (int j = 0; j < c.film.height; j++)

@@ -11,6 +11,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["PATHTRACE_HIP_PLAN"] = "caller"   # this probe times plans OTHER than the library's: every call below is one batch
 import pathtrace_amd as pt
 from pathtrace_amd.distributed import measure_tile_costs, tiles_for_rank
 
@@ -38,7 +39,7 @@ def cut(weights):
     return [x for x in sizes if x > 0]
 
 
-CAP = int(os.environ.get("PT_PLAN_CAP", "66400000"))   # path slots per batch (bench.py MAX_BATCH_PATHS)
+CAP = int(os.environ.get("PT_PLAN_CAP", "66400000"))   # path slots per batch (the library's PT_PLAN_MAX_PATHS is 199 M)
 COUNTS = [int(x) for x in os.environ.get("PT_PLAN_COUNTS", "3,4,5,6,9,12,15,18,24,33").split(",")]
 WEIGHTS = [[float(x) for x in w.split(":")] for w in os.environ.get("PT_PLAN_WEIGHTS", "").split(",") if w]   # e.g. "5:3,3:5,2:1:1": unequal batches
 for plan in COUNTS + WEIGHTS:

@@ -20,11 +20,11 @@ SC=""
 if [ -n "$SCENE" ]; then SC="--scene $R/scenes/$SCENE --no-configs --no-scaling-proxy"; fi
 timeout -k 10 800 python3 "$R/bench.py" $SC > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench.err" || { echo "bench failed"; tail -5 "$OUT/${TAG}_bench.err"; exit 1; }
 cd /tmp
-Q="--no-cpu-baseline --no-configs --no-scaling-proxy"
+Q="--no-cpu-baseline --no-configs --no-scaling-proxy --no-plugin-path"
 if [ -n "$SCENE" ]; then Q="$Q --scene $R/scenes/$SCENE"; fi
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof" -- python3 "$R/bench.py" $Q > "$OUT/${TAG}_prof.log" 2>&1 || { echo "kernel-trace failed"; tail -5 "$OUT/${TAG}_prof.log"; exit 1; }
 export PATHTRACE_HIP_LANES=1
-export PT_BENCH_GROUP=2   # 32 spp per launch: the batches of the headline run
+export PT_BENCH_MAX_PATHS=66355200   # 1920 x 1080 x 32 slots: 32 spp per launch, comparable from round to round
 # 2b. the same kernel-trace statistics with ONE batch in flight: every launch alone on the chip, so the table's average duration of a
 #     kernel is the one bench.py's roofline block uses (its own one-lane pass)
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_prof1" -- python3 "$R/bench.py" --steps 8 --warmup 1 $Q > "$OUT/${TAG}_prof1.log" 2>&1 || { echo "one-lane kernel-trace failed"; tail -5 "$OUT/${TAG}_prof1.log"; exit 1; }
@@ -34,6 +34,6 @@ timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${TAG}_pmc_insts" -- python3 "$R/bench.py" --steps 4 --warmup 1 $Q > "$OUT/${TAG}_pmc_insts.log" 2>&1 || { echo "pmc insts failed"; tail -5 "$OUT/${TAG}_pmc_insts.log"; exit 1; }
 # 5. where a wave's life goes, every kernel alone on the chip (one lane): parked on s_waitcnt / barriers, stalled at issue, executing
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/${TAG}_pmc_wait" -- python3 "$R/bench.py" --steps 4 --warmup 1 $Q > "$OUT/${TAG}_pmc_wait.log" 2>&1 || { echo "pmc wait failed"; tail -5 "$OUT/${TAG}_pmc_wait.log"; exit 1; }
-unset PATHTRACE_HIP_LANES PT_BENCH_GROUP
+unset PATHTRACE_HIP_LANES PT_BENCH_MAX_PATHS
 cd "$R"
 python3 tools/summarize_profiles.py "$TAG" "$OUT"
