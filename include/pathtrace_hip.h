@@ -189,6 +189,13 @@ int pt_render_tiles_async(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, in
  * launch plan above; what Renderer::Renderer's framebuffer allocation (renderer.h:121-133) is to the reference.  Optional:
  * the first render call does it otherwise, inside the caller's timed region.  Returns 0, < 0 on failure. */
 int pt_reserve(pt_ctx *ctx, int64_t pixels, int32_t samples);
+/* ABI v6.  Warm the context up before a timed render: one-sample passes over the given rects (n_rects = 0: the whole film) on
+ * every lane for at least `min_ms` milliseconds, then framebuffer and counters are cleared (call it before the first render,
+ * after pt_reserve).  A fresh process's first render otherwise pays the code objects' first launches, the first touch of the
+ * freshly allocated streams and the clock ramp of an idle GPU: +5 ms on a 104 ms render of 1080p x 256 spp, measured
+ * (profiles/experiments/r05_cold_start.jsonl); Tiled::start_render's thread spawn is outside its timed region as well
+ * (renderer.h:553-603). */
+int pt_prime(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, int32_t min_ms);
 /* The plan of the last render call / pt_reserve and the state of the streams. */
 int pt_get_plan(pt_ctx *ctx, pt_plan *out);
 /* The rule itself (host only, no device): samples per batch of a call of pixels x samples with `path_slots` slots per batch on
@@ -281,9 +288,9 @@ pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, i
                           int32_t block_w, int32_t block_h);
 void pt_multi_destroy(pt_multi *m);
 int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp_end);
-/* ABI v6: pt_reserve for every device's share of the film; seconds from pt_multi_render_async's entry until the last
+/* ABI v6: pt_reserve + pt_spec_wait + pt_prime (prime_ms, 0 = none) for every device's share of the film; seconds from pt_multi_render_async's entry until the last
  * device finished (< 0 while running); timed wait (1 idle, 0 timed out). */
-int pt_multi_reserve(pt_multi *m, int32_t samples);
+int pt_multi_reserve(pt_multi *m, int32_t samples, int32_t prime_ms);
 double pt_multi_render_seconds(pt_multi *m);
 int pt_multi_wait_for(pt_multi *m, int32_t timeout_ms);
 int pt_multi_poll(pt_multi *m, uint64_t *samples_done, uint64_t *rays_done);      /* 1 done, 0 running, < 0 error */

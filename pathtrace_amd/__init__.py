@@ -109,7 +109,7 @@ class HostConfig(C.Structure):
 
 
 # every symbol include/pathtrace_hip.h declares
-EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_reserve", "pt_get_plan", "pt_plan_batches", "pt_render_seconds", "pt_wait_for",
+EXPORTS = ["pt_create", "pt_destroy", "pt_render_async", "pt_render_tiles_async", "pt_reserve", "pt_prime", "pt_get_plan", "pt_plan_batches", "pt_render_seconds", "pt_wait_for",
            "pt_multi_reserve", "pt_multi_render_seconds", "pt_multi_wait_for", "pt_poll", "pt_wait", "pt_read_framebuffer", "pt_snapshot_framebuffer",
            "pt_clear_framebuffer", "pt_get_counters", "pt_device_framebuffer", "pt_set_device_framebuffer",
            "pt_get_stream", "pt_set_stream", "pt_set_profiling", "pt_get_kernel_times", "pt_set_lanes", "pt_measure_tile_costs", "pt_spec_header", "pt_spec_status", "pt_spec_wait", "pt_spec_info", "pt_spec_build_check", "pt_spec_build_info",
@@ -146,7 +146,8 @@ def lib():
     L.pt_render_seconds.argtypes = [vp]
     L.pt_render_seconds.restype = C.c_double
     L.pt_wait_for.argtypes = [vp, C.c_int32]
-    L.pt_multi_reserve.argtypes = [vp, C.c_int32]
+    L.pt_multi_reserve.argtypes = [vp, C.c_int32, C.c_int32]
+    L.pt_prime.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     L.pt_multi_render_seconds.argtypes = [vp]
     L.pt_multi_render_seconds.restype = C.c_double
     L.pt_multi_wait_for.argtypes = [vp, C.c_int32]
@@ -378,6 +379,12 @@ class Renderer:
         set-up, like the scene upload; the first render call does it otherwise."""
         _check(lib().pt_reserve(self._h, int(pixels), int(samples)), "pt_reserve")
 
+    def prime(self, min_ms: int = 50, rects=None):
+        """Warm-up before a timed render (pt_prime): one-sample passes on every lane for min_ms, then everything is cleared."""
+        flat = [int(v) for r in (rects or []) for v in r]
+        arr = (C.c_int32 * len(flat))(*flat) if flat else None
+        _check(lib().pt_prime(self._h, len(flat) // 4, arr, int(min_ms)), "pt_prime")
+
     def plan(self) -> dict:
         """The library's launch plan of the last render call / reserve (pt_get_plan)."""
         p = Plan()
@@ -525,8 +532,8 @@ class MultiRenderer:
     def render_async(self, spp_begin, spp_end):
         _check(lib().pt_multi_render_async(self._h, spp_begin, spp_end), "pt_multi_render_async")
 
-    def reserve(self, samples: int):
-        _check(lib().pt_multi_reserve(self._h, int(samples)), "pt_multi_reserve")
+    def reserve(self, samples: int, prime_ms: int = 0):
+        _check(lib().pt_multi_reserve(self._h, int(samples), int(prime_ms)), "pt_multi_reserve")
 
     def render_seconds(self) -> float:
         return float(lib().pt_multi_render_seconds(self._h))

@@ -1293,6 +1293,26 @@ extern "C" int pt_render_tiles_async(pt_ctx *c, int32_t n_rects, const int32_t *
 
 extern "C" int pt_wait(pt_ctx *c);
 extern "C" int pt_clear_framebuffer(pt_ctx *c);
+// Warm-up before a timed render (include/pathtrace_hip.h): one-sample passes over the rects, every lane, at least min_ms.
+extern "C" int pt_prime(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_t min_ms)
+{
+    if (!c || n_rects < 0 || (n_rects > 0 && !rects)) { set_err("pt_prime: bad argument"); return -1; }
+    const int32_t whole[4] = {0, 0, c->cfg.width, c->cfg.height};
+    if (n_rects == 0) { n_rects = 1; rects = whole; }
+    const pt_plan keep = c->plan;
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
+        for (int l = 0; l < c->n_lanes; l++)
+            if (render_tiles(c, n_rects, rects, 0, 1, false)) return -1;
+        if (pt_wait(c)) return -1;
+    } while (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < (double)min_ms);
+    {   // the plan a caller reads back is the one of its own calls, not of the warm-up's
+        pt_plan now = c->plan;
+        c->plan = keep;
+        c->plan.path_slots = now.path_slots; c->plan.stream_bytes = now.stream_bytes; c->plan.hbm_free_bytes = now.hbm_free_bytes; c->plan.grown = now.grown;
+    }
+    return pt_clear_framebuffer(c);
+}
 // The planner of a tile-partitioned render: World::hit queries PERFORMED (extension rays + the shadow rays
 // of hits that got a shadow record: pt_counters::rays_traced) for `spp` samples per pixel of every rect, counted per rect
 // in ONE pass over all of them -- the rects are rendered together as ordinary wavefront batches and k_tally attributes

@@ -302,7 +302,7 @@ extern "C" int pt_multi_render_async(pt_multi *m, int32_t spp_begin, int32_t spp
     });
 }
 
-extern "C" int pt_multi_reserve(pt_multi *m, int32_t samples)
+extern "C" int pt_multi_reserve(pt_multi *m, int32_t samples, int32_t prime_ms)
 {
     if (!m || samples < 1) { merr("pt_multi_reserve: bad argument"); return -1; }
     return on_every_device(m, "pt_multi_reserve", [&](size_t i) {
@@ -310,7 +310,7 @@ extern "C" int pt_multi_reserve(pt_multi *m, int32_t samples)
         if (!px) return 0;
         if (pt_reserve(m->ctx[i], px, samples)) return -1;
         (void)pt_spec_wait(m->ctx[i]);   // every device on its scene's own kernels before the first timed launch (-1: generic kernels)
-        return 0;
+        return prime_ms > 0 ? pt_prime(m->ctx[i], (int32_t)(m->rects[i].size() / 4), m->rects[i].data(), prime_ms) : 0;
     });
 }
 

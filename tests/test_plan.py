@@ -7,7 +7,7 @@ import pathtrace_amd as pt
 def test_abi_version_and_plan_symbols():
     L = pt.lib()
     assert L.pt_abi_version() == 6
-    for name in ("pt_reserve", "pt_get_plan", "pt_plan_batches", "pt_render_seconds", "pt_wait_for", "pt_multi_reserve",
+    for name in ("pt_reserve", "pt_prime", "pt_get_plan", "pt_plan_batches", "pt_render_seconds", "pt_wait_for", "pt_multi_reserve",
                  "pt_multi_render_seconds", "pt_multi_wait_for"):
         assert hasattr(L, name), name
 

@@ -101,21 +101,42 @@ def test_provenance_names_the_compiler_and_survives_a_hostile_environment(monkey
     assert info["own_compiler"] in (True, False) and info["producer"]
 
 
-@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume", "three_orbs", "textured_room"])
-def test_the_table_folds_into_the_code(scene, tmp_path, monkeypatch):
-    # The point of the per-scene build: the op loop unrolls completely and the table becomes literals.  LLVM sizes the unrolled
-    # loop BEFORE it folds the per-kind dispatch and, past a threshold, quietly keeps a run-time loop over a table in constant
-    # memory that carries every leaf body (round 4: the volume scene's k_connect, 18.7 against 16.2 ms).  No instruction of the
-    # module may refer to the table.
+def _table_survives(code_object):
+    """Does the module still READ the table at run time?  A reference to it never shows by name in a disassembly (the address is
+    s_getpc_b64 plus a resolved immediate, .rodata is not disassembled), so look at what changes when the table survives: an
+    object symbol for it in the symbol table, and any s_getpc_b64 at all -- the per-scene kernels call nothing and address no
+    constant data, a fully folded module has neither."""
     import os
     import subprocess
     from pathtrace_amd import build as ptb
 
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(ptb.HIPCC))), "lib", "llvm", "bin")
+    syms = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-sW", str(code_object)], capture_output=True, text=True).stdout
+    text = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", str(code_object)], capture_output=True, text=True).stdout
+    assert "k_connect" in text and "k_extend" in text and "FUNC" in syms
+    table_symbol = any("kSpecW" in line and "OBJECT" in line for line in syms.splitlines())
+    return table_symbol or "s_getpc_b64" in text
+
+
+@pytest.mark.parametrize("scene", ["cornell_box", "cornell_box_with_volume", "three_orbs", "textured_room"])
+def test_the_table_folds_into_the_code(scene, tmp_path, monkeypatch):
+    # The point of the per-scene build: the op loop unrolls completely and the table becomes literals.  LLVM sizes the unrolled
+    # loop BEFORE it folds the per-kind dispatch and, past a threshold, quietly keeps a run-time loop over a table in constant
+    # memory that carries every leaf body (round 4: the volume scene's k_connect, 18.7 against 16.2 ms).
     out = tmp_path / "m.co"
     monkeypatch.setenv("PATHTRACE_HIP_SPEC_DUMP", str(out))
     monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_FOLD=1")   # a key nothing has cached: this build runs now
     sc = pt.Scene(scene_path(scene), 64, 36)
     assert pt.spec_build_check(sc, 4) > 20000
-    objdump = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(ptb.HIPCC))), "lib", "llvm", "bin", "llvm-objdump")
-    text = subprocess.run([objdump, "-d", str(out)], capture_output=True, text=True).stdout
-    assert "k_connect" in text and "k_extend" in text and "kSpecW" not in text
+    assert not _table_survives(out)
+
+
+def test_the_fold_check_trips_when_llvm_keeps_the_loop(tmp_path, monkeypatch):
+    # negative control (ADVICE r4): the same module built with LLVM's own default threshold restored to a low value keeps a
+    # run-time loop over the table -- the check above must see it
+    out = tmp_path / "m.co"
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_DUMP", str(out))
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC_FLAGS", "-DPT_TEST_FOLD=2 -mllvm -pragma-unroll-threshold=2000")
+    sc = pt.Scene(scene_path("cornell_box_with_volume"), 64, 36)
+    assert pt.spec_build_check(sc, 4) > 20000
+    assert _table_survives(out)

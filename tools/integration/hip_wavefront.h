@@ -230,13 +230,14 @@ public:
         if (devices.size() > 1) {
             multi = pt_multi_create(&flat.desc, &pc, (int32_t)devices.size(), devices.data(), std::max(config.block_width, 1), std::max(config.block_height, 1));
             ASSERT(multi != nullptr, pt_last_error());
-            ASSERT(pt_multi_reserve(multi, std::max(config.samples, 1)) == 0, pt_last_error());
+            ASSERT(pt_multi_reserve(multi, std::max(config.samples, 1), 50) == 0, pt_last_error());   // + per-scene build + 50 ms warm-up per device
         } else {
             if (devices.size() == 1) pc.device = devices[0];
             ctx = pt_create(&flat.desc, &pc);
             ASSERT(ctx != nullptr, pt_last_error());                          // the reference's error style (types.h:5-14)
             ASSERT(pt_reserve(ctx, (int64_t)film.width * film.height, std::max(config.samples, 1)) == 0, pt_last_error());
             (void)pt_spec_wait(ctx);                                          // -1: the generic kernels render
+            ASSERT(pt_prime(ctx, 0, nullptr, 50) == 0, pt_last_error());      // a fresh process's first render is ~5 % slower otherwise
         }
         staging.resize((size_t)film.width * film.height * 3);
         completed = false;
