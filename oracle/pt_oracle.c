@@ -491,13 +491,23 @@ static int sphere_hit(const prim_t *s, const ray_t *r, float t_min, float t_max,
 static int prim_hit(const pto_scene *sc, const prim_t *p, const ray_t *r, float t0, float t1, hitrec *rec,
                     rngctx *rc, int vol_ordinal);
 
+/* Free-flight draws one constant_medium::hit call can make: its own, and -- when its boundary is a constant_medium itself
+   (volume.h:10 takes any hittable) -- those of the two boundary->hit calls in front of it.  Stream mode gives every draw of
+   a traversal a dimension of its own: slot_base .. + draws - 1, the first boundary call's first, then the second's, then
+   this medium's own (the order the reference makes them in). */
+static int volume_draws(const pto_scene *sc, const prim_t *p)
+{
+    if (p->type != PTO_PRIM_VOLUME) return 0;
+    return 2 * volume_draws(sc, &sc->prims[p->boundary]) + 1;
+}
 static int volume_hit(const pto_scene *sc, const prim_t *p, const ray_t *r, float t_min, float t_max, hitrec *rec,
                       rngctx *rc, int vol_ordinal)
 {   /* volume.h:29-93 */
     hitrec rec1, rec2;
     const prim_t *b = &sc->prims[p->boundary];
-    if (prim_hit(sc, b, r, -FLT_MAX, FLT_MAX, &rec1, rc, -1)) {
-        if (prim_hit(sc, b, r, (float)((double)rec1.t + 0.0001), FLT_MAX, &rec2, rc, -1)) {
+    const int nb = volume_draws(sc, b);
+    if (prim_hit(sc, b, r, -FLT_MAX, FLT_MAX, &rec1, rc, vol_ordinal)) {
+        if (prim_hit(sc, b, r, (float)((double)rec1.t + 0.0001), FLT_MAX, &rec2, rc, vol_ordinal + nb)) {
             if (rec1.t < t_min) rec1.t = t_min;
             if (rec2.t > t_max) rec2.t = t_max;
             if (rec1.t >= rec2.t) return 0;
@@ -508,7 +518,7 @@ static int volume_hit(const pto_scene *sc, const prim_t *p, const ray_t *r, floa
             if (rc->mode == PTO_MODE_MT) {
                 hit_distance = (float)((double)(-(1 / p->density)) * log(rnd(rc, 0)));
             } else {
-                float u = (float)rnd(rc, rc->vol_dim_base + (uint32_t)vol_ordinal);
+                float u = (float)rnd(rc, rc->vol_dim_base + (uint32_t)(vol_ordinal + 2 * nb));
                 hit_distance = (-(1 / p->density)) * ptm_logf(u);
             }
             if (hit_distance < distance_inside) {
@@ -854,7 +864,9 @@ pto_scene *pto_scene_create_textured(const pto_material *mats, int nmat, const p
         q->prim = p->prim;
         q->fwd = affine_compose(p->scale, p->rotate, p->translate);
         q->inv = affine_inverse(&q->fwd);
-        q->vol_ordinal = (sc->prims[p->prim].type == PTO_PRIM_VOLUME) ? sc->nvol++ : -1;
+        /* first stream-mode draw slot of this instance's traversal; nvol = slots of all volume instances */
+        q->vol_ordinal = -1;
+        if (sc->prims[p->prim].type == PTO_PRIM_VOLUME) { q->vol_ordinal = sc->nvol; sc->nvol += volume_draws(sc, &sc->prims[p->prim]); }
         /* instance ctor: bbox of the 8 transformed corners (primitive.h:266-296) */
         aabb pb = prim_bbox(sc, &sc->prims[p->prim]);
         v3 mn = V(FLT_MAX, FLT_MAX, FLT_MAX), mx = V(-FLT_MAX, -FLT_MAX, -FLT_MAX);

@@ -311,7 +311,7 @@ def spec_build_info(scene: "Scene", light_samples: int = 4) -> dict:
         raise PathtraceError(f"pt_spec_build_info: {last_error()}")
     buf = C.create_string_buffer(n + 1)
     lib().pt_spec_build_info(C.byref(scene.desc), light_samples, buf, n + 1)
-    return json.loads(buf.value.decode())
+    return json.loads(buf.value.decode(errors="replace"))
 
 
 def load_config(path: str = None, text: str = None) -> HostConfig:
@@ -460,7 +460,7 @@ class Renderer:
             raise PathtraceError(f"pt_spec_info: {last_error()}")
         buf = C.create_string_buffer(n + 1)
         lib().pt_spec_info(self._h, buf, n + 1)
-        return json.loads(buf.value.decode())
+        return json.loads(buf.value.decode(errors="replace"))
 
     def set_profiling(self, on: bool):
         _check(lib().pt_set_profiling(self._h, int(on)), "pt_set_profiling")

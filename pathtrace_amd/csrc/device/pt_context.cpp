@@ -182,6 +182,19 @@ static DRect make_rect(float x0, float z0, float x1, float z1, float y, int mat,
     return r;
 }
 
+// Free-flight draws one constant_medium::hit can make (volume.h:70): its own and, when its boundary is a medium too, those of
+// the two boundary->hit calls in front of it -- the dimension slots a volume instance's traversal owns in stream mode, in the
+// reference's order: first boundary call, second boundary call, own draw (oracle/pt_oracle.c volume_draws, same rule).
+static int volume_draws(const pt_scene_desc *sc, int pi)
+{
+    int n = 0;
+    for (int depth = 0; pi >= 0 && pi < sc->n_primitives && sc->primitives[pi].type == PT_PRIM_VOLUME && depth < 8; depth++) {
+        n = 2 * n + 1;
+        pi = sc->primitives[pi].boundary;
+    }
+    return n;
+}
+
 // bvh_node tree -> sweep program (pt_device.h).  `pending_push` is the slot the NEXT emitted op must push into.
 static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<DOp> &ops, int &max_depth, int &pending_push)
 {
@@ -221,7 +234,9 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
             memcpy(op.g, p.center, 12); op.g[3] = p.radius;
             break;
         case PT_PRIM_VOLUME: {
+            if (p.boundary < 0 || p.boundary >= sc->n_primitives) return -1;
             const pt_primitive &bd = sc->primitives[p.boundary];
+            if (bd.type == PT_PRIM_VOLUME && (bd.boundary < 0 || bd.boundary >= sc->n_primitives)) return -1;
             if (bd.type == PT_PRIM_BOX) {
                 op.kind = OP_LEAF_VOLBOX;
                 memcpy(op.g, bd.p0, 12); memcpy(op.g + 3, bd.p1, 12);
@@ -232,7 +247,19 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
                 op.g[6] = p.density;
             } else if (bd.type == PT_PRIM_RECT) {
                 op.kind = OP_LEAF_NONE;
-            } else return -2;   // a medium inside a medium: refused loudly by the caller
+            } else if (bd.type == PT_PRIM_VOLUME) {
+                // a medium whose boundary is a medium: the outer's two boundary queries are two scattering events of the inner
+                // one (volume.h:29-93 twice); one level of nesting is carried, the inner's own boundary being a box or a sphere
+                const pt_primitive &ib = sc->primitives[bd.boundary];
+                int32_t shape = 0;
+                if (ib.type == PT_PRIM_BOX) { shape = 1; memcpy(op.g, ib.p0, 12); memcpy(op.g + 3, ib.p1, 12); }
+                else if (ib.type == PT_PRIM_SPHERE) { shape = 2; memcpy(op.g, ib.center, 12); op.g[3] = ib.radius; }
+                else if (ib.type == PT_PRIM_RECT) shape = 0;   // the inner medium is never hit, so neither is the outer one
+                else return -2;                                // three media deep: refused loudly by the caller
+                op.kind = shape ? OP_LEAF_VOLVOL : OP_LEAF_NONE;
+                op.g[6] = p.density; op.g[8] = bd.density;
+                memcpy(&op.g[9], &shape, 4);
+            } else return -2;
             break;
         }
         default: return -1;
@@ -338,11 +365,11 @@ struct HostProgram {
 static int build_program(const pt_scene_desc *sc, HostProgram &hp)
 {
     if (!sc || sc->n_instances < 1 || sc->n_primitives < 1 || sc->n_nodes < 1) { set_err("pt_create: empty scene"); return -1; }
-    std::vector<int32_t> vol_ordinal(sc->n_instances, -1);   // ordinal among volume instances (stream RNG dimension slot)
+    std::vector<int32_t> vol_ordinal(sc->n_instances, -1);   // first stream RNG dimension slot of a volume instance's traversal
     for (int i = 0, nvol = 0; i < sc->n_instances; i++) {
         const int pi = sc->instances[i].primitive;
         if (pi < 0 || pi >= sc->n_primitives) { set_err("pt_create: instance %d: bad primitive", i); return -1; }
-        if (sc->primitives[pi].type == PT_PRIM_VOLUME) vol_ordinal[i] = nvol++;
+        if (sc->primitives[pi].type == PT_PRIM_VOLUME) { vol_ordinal[i] = nvol; nvol += volume_draws(sc, pi); }
     }
     std::vector<DOp> &ops = hp.ops;
     int max_depth = 0;
@@ -355,7 +382,7 @@ static int build_program(const pt_scene_desc *sc, HostProgram &hp)
             }
     int pending_push = -1;
     if (emit_ops(sc, 0, 0, ops, max_depth, pending_push)) {
-        set_err("pt_create: malformed BVH, or a constant_medium whose boundary is another constant_medium");
+        set_err("pt_create: malformed BVH, or constant_mediums nested three deep (a medium whose boundary is a medium whose boundary is a medium)");
         return -1;
     }
     if (max_depth > 64) {
@@ -363,7 +390,7 @@ static int build_program(const pt_scene_desc *sc, HostProgram &hp)
         return -1;
     }
     for (DOp &op : ops)
-        if (op.kind == OP_LEAF_VOLBOX || op.kind == OP_LEAF_VOLSPHERE) { int32_t vo = vol_ordinal[op.a]; memcpy(&op.g[7], &vo, 4); }
+        if (op.kind == OP_LEAF_VOLBOX || op.kind == OP_LEAF_VOLSPHERE || op.kind == OP_LEAF_VOLVOL) { int32_t vo = vol_ordinal[op.a]; memcpy(&op.g[7], &vo, 4); }
     if (ops.size() >= (1u << 22)) { set_err("pt_create: traversal program too long (%zu ops)", ops.size()); return -1; }
     ops.push_back(DOp{});   // padding op (never executed)
     // the fast program (pt_kernels.hip world_hit_fast): the same list without the COMBINE ops (the fold over the leaves
@@ -425,6 +452,7 @@ static int build_program(const pt_scene_desc *sc, HostProgram &hp)
             return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
         };
         hp.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
+        for (const DOp &op : ops) if (op.kind == OP_LEAF_VOLVOL) hp.tame = 0;   // a medium in a medium: the general sweep carries it
         for (int oi = 0; oi < (int)ops.size(); oi++) {
             DOp &op = ops[oi];
             if (op.kind == OP_ENTER) {   // world_hit_fast takes min / max of the slab products: the box must be ordered and finite
@@ -589,8 +617,7 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             d.cx = p.center[0]; d.cy = p.center[1]; d.cz = p.center[2]; d.radius = p.radius;
             break;
         case PT_PRIM_VOLUME:
-            if (p.boundary < 0 || p.boundary >= i || sc->primitives[p.boundary].type == PT_PRIM_VOLUME ||
-                p.phase_material < 0 || p.phase_material >= sc->n_materials) {
+            if (p.boundary < 0 || p.boundary >= i || p.phase_material < 0 || p.phase_material >= sc->n_materials) {
                 set_err("pt_create: volume primitive %d: bad boundary / phase material", i);
                 return -1;
             }
@@ -618,7 +645,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
         memcpy(d.inv, p.inv, sizeof d.inv);
         memcpy(d.fwd, p.fwd, sizeof d.fwd);
         d.prim = p.primitive;
-        d.vol_ordinal = (prims[p.primitive].type == PT_PRIM_VOLUME) ? nvol++ : -1;
+        d.vol_ordinal = -1;
+        if (prims[p.primitive].type == PT_PRIM_VOLUME) { d.vol_ordinal = nvol; nvol += volume_draws(sc, p.primitive); }
         {
             auto is_ident = [](const float *m) {
                 return m[0] == 1.0f && m[5] == 1.0f && m[10] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f &&

@@ -88,6 +88,9 @@ enum {
     OP_LEAF_VOLSPHERE = 8, // constant_medium with a sphere boundary: as OP_LEAF_SPHERE + f[18] = density, f[19] = bits(vol_ord)
     OP_LEAF_NONE = 9,    // a leaf that never reports a hit: constant_medium whose boundary is a rect (its second boundary hit
                          // beyond t1 + 0.0001 cannot exist, or both are NaN and the medium test fails: volume.h:33-46, 70-75)
+    OP_LEAF_VOLVOL = 10, // constant_medium whose boundary is a constant_medium (volume.h:10 takes any hittable): f[12..17] = the INNER
+                         // medium's boundary (box p0 p1, or sphere centre + radius), f[18] = outer density, f[19] = bits(first draw slot),
+                         // f[20] = inner density, f[21] = bits(inner boundary: 1 box, 2 sphere).  General sweep only (the scene is not tame)
 };
 struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in the device array
     // first half: everything an op needs FIRST (header + node box or instance matrix)

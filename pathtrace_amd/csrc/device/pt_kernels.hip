@@ -92,6 +92,12 @@ namespace ptd {
 #ifndef PT_SYM_BOUNDS
 #define PT_SYM_BOUNDS 1      // per-scene build: faces centred on the local origin test |xh| - x1 instead of two differences (0: the A/B)
 #endif
+#ifndef PT_VOL_SHARED
+#define PT_VOL_SHARED 1      // fast sweep, constant_medium on a box: both boundary queries from one evaluation of the six sides (0: box_hit_fast twice, the A/B)
+#endif
+#ifndef PT_VOL_LAZY_DRAW
+#define PT_VOL_LAZY_DRAW 1   // ... and the free-flight draw only in waves where some ray crosses the medium (0: every wave draws, the A/B)
+#endif
 #ifndef PT_BOX3
 #define PT_BOX3 0            // EXPERIMENT, not exact (DESIGN.md 4.2 "one fold per box axis"): per box axis only the face a convex box can be hit on
                              // first (the near plane when its t >= t_min, else the far one) is folded.  1: no guard at all -- the upper bound
@@ -374,6 +380,21 @@ DEVI bool medium_decide(bool hit, float t1v, float t2v, v3 Bl, float density, fl
     t_out = t1v + hit_distance / dlen;
     return hit && (hit_distance < distance_inside);
 }
+// constant_medium::hit (volume.h:29-93) called with the range (t_min, t_max): the clamp, the draw u of this call, the inside test.
+// medium_decide is this with the integrator's range; a medium that is the BOUNDARY of another medium is called with
+// (-FLT_MAX, FLT_MAX) and (rec1.t + 0.0001, FLT_MAX) (volume.h:38-40).
+DEVI bool medium_decide_in(bool hit, float t1v, float t2v, float t_min, float t_max, v3 Bl, float density, float u, float &t_out)
+{
+    t1v = (t1v < t_min) ? t_min : t1v;
+    t2v = (t2v > t_max) ? t_max : t2v;
+    hit = hit && !(t1v >= t2v);
+    t1v = (t1v < 0) ? 0.0f : t1v;
+    const float dlen = vlen(Bl);
+    const float distance_inside = (t2v - t1v) * dlen;
+    const float hit_distance = (-(1 / density)) * ptm_logf(u);
+    t_out = t1v + hit_distance / dlen;
+    return hit && (hit_distance < distance_inside);
+}
 // ---- leaf tests on NR rays that share one origin (NR = 1: extension ray; NR = light_samples: the shadow rays of
 // one hit).  The local origin (ray::apply ray.h:20-24) and every numerator that depends only on it are computed
 // once; each ray's own arithmetic is exactly the single-ray sequence.
@@ -647,6 +668,38 @@ DEVI void world_hit_n(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR],
                     hit = hit && sphere_t(oc, c, Bl, (float)((double)t1v + 0.0001), FLT_MAX, t2v);
                     const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)w1[7]);
                     hit = medium_decide(hit, t1v, t2v, Bl, OPF(18), u, tv) && (pc >= skip[r]);
+                    cur_id[r] = hit ? op_id_base : -1;
+                    cur_t[r] = hit ? tv : cur_t[r];
+                }
+            } else if (GA && kind == OP_LEAF_VOLVOL) {
+                // constant_medium whose boundary is a constant_medium (volume.h:10: any hittable).  boundary->hit(r, -FLT_MAX,
+                // FLT_MAX, rec1) and boundary->hit(r, rec1.t + 0.0001, FLT_MAX, rec2) are two scattering events of the INNER medium
+                // (each: its own boundary hit twice -- the same two values both times -- its clamp to the caller's range, a draw
+                // of its own), then the outer medium's clamp, draw and inside test.  The three draws of a traversal have
+                // consecutive dimensions in the reference's order (pt_context.cpp volume_draws).
+                const bool ibox = w1[9] == 1;
+                const float dens_out = OPF(18), dens_in = OPF(20);
+                const v3 oc = vsub(Al, V(q0[0], q0[1], q0[2]));
+                const float cs = vdot(oc, oc) - q1[0] * q1[0];
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const v3 Bl = XF_DIR(B[r]);
+                    float b1 = 0.0f, b2 = 0.0f;   // the innermost boundary's two hits: the same for both calls of the inner medium
+                    bool bh;
+                    if (ibox) {
+                        int f1, f2;
+                        box_hit_shared(q0, q1, Al, Bl, -FLT_MAX, FLT_MAX, b1, f1);
+                        box_hit_shared(q0, q1, Al, Bl, (float)((double)b1 + 0.0001), FLT_MAX, b2, f2);
+                        bh = (f1 >= 0) && (f2 >= 0);
+                    } else {
+                        bh = sphere_t(oc, cs, Bl, -FLT_MAX, FLT_MAX, b1);
+                        bh = bh && sphere_t(oc, cs, Bl, (float)((double)b1 + 0.0001), FLT_MAX, b2);
+                    }
+                    const uint32_t d0 = vol_dim_base[r] + (uint32_t)w1[7];
+                    float t1v = 0.0f, t2v = 0.0f, tv;
+                    bool hit = medium_decide_in(bh, b1, b2, -FLT_MAX, FLT_MAX, Bl, dens_in, rndf(k0, k1, d0), t1v);
+                    hit = hit && medium_decide_in(bh, b1, b2, (float)((double)t1v + 0.0001), FLT_MAX, Bl, dens_in, rndf(k0, k1, d0 + 1u), t2v);
+                    hit = medium_decide(hit, t1v, t2v, Bl, dens_out, rndf(k0, k1, d0 + 2u), tv) && (pc >= skip[r]);
                     cur_id[r] = hit ? op_id_base : -1;
                     cur_t[r] = hit ? tv : cur_t[r];
                 }
@@ -975,17 +1028,10 @@ DEVI float fdiv_q_nofix(float n, float d, float r)
 // the closest-hit rule folded in.  PLANE as in rect_axes; num = plane - local origin's plane component; r = fdiv_rcp(dpl);
 // skip <= 0: the ray is not masked (tree programs pass skipf - pc, flat programs a constant).
 // the closest-hit rule on one rect face given its quotient t (see face_fold)
-template <int PLANE, bool IEEE, bool SKIP>
-DEVI void face_fold_t(float x0, float z0, float x1, float z1, float t, float ox, float oz, v3 Bl, float skip, int id,
-                      float &cur_t, int &cur_id, float &chk)
+// rect::hit's bounds test on a hit point (xh, zh) (primitive.h:200-205): positive iff "xh < x0 || xh > x1 || zh < z0 || zh > z1";
+// NaN coordinates compare false there and are ignored by the maxima here.
+DEVI float side_excess(float x0, float z0, float x1, float z1, float xh, float zh)
 {
-    const float T_MIN = 0.001f;
-    float dx, dpl, dz;
-    rect_axes<PLANE>(Bl, dx, dpl, dz);
-    const float xh = ox + t * dx;
-    const float zh = oz + t * dz;
-    // reject iff t < t_min || xh < x0 || xh > x1 || zh < z0 || zh > z1 (primitive.h:193-205; NaN compares false: not rejected) or the
-    // current hit is strictly closer -- one maximum, decided by its sign
     float ex, ez;
 #if defined(PT_SPEC_HEADER) && PT_SYM_BOUNDS
     // Bounds symmetric about the local origin (x0 == -x1: every rect and box the scene format centres, scene_parser.h:131-170;
@@ -997,12 +1043,27 @@ DEVI void face_fold_t(float x0, float z0, float x1, float z1, float t, float ox,
 #else
     ex = fmaxf(x0 - xh, xh - x1); ez = fmaxf(z0 - zh, zh - z1);
 #endif
-    float e = fmaxf(fmaxf(T_MIN - t, t - cur_t), fmaxf(ex, ez));
+    return fmaxf(ex, ez);
+}
+template <int PLANE, bool IEEE, bool SKIP>
+DEVI void face_fold_t(float x0, float z0, float x1, float z1, float t, float ox, float oz, v3 Bl, float skip, int id,
+                      float &cur_t, int &cur_id, float &chk)
+{
+    const float T_MIN = 0.001f;
+    float dx, dpl, dz;
+    rect_axes<PLANE>(Bl, dx, dpl, dz);
+    const float xh = ox + t * dx;
+    const float zh = oz + t * dz;
+    // reject iff t < t_min || xh < x0 || xh > x1 || zh < z0 || zh > z1 (primitive.h:193-205; NaN compares false: not rejected) or the
+    // current hit is strictly closer -- one maximum, decided by its sign
+    float e = fmaxf(fmaxf(T_MIN - t, t - cur_t), side_excess(x0, z0, x1, z1, xh, zh));
     if (SKIP) e = fmaxf(e, skip);
     const bool take = !(e > 0.0f);
     cur_t = take ? t : cur_t;
     cur_id = take ? id : cur_id;
-    if (IEEE) chk = __builtin_fmaf(0.0f, cur_t, chk);   // an accepted NaN t (0 / 0): the general sweep decides
+    // an accepted NaN t (0 / 0): the general sweep decides.  Only the ACCEPTED t feeds the tracker: cur_t itself is -inf for a lane
+    // that missed the root box of a flat program, and 0 * -inf would send every wave at the scene's silhouette to the general sweep
+    if (IEEE) chk = __builtin_fmaf(0.0f, take ? t : 0.0f, chk);
 }
 template <int PLANE, bool IEEE, bool SKIP>
 DEVI void face_fold(float x0, float z0, float x1, float z1, float num, float ox, float oz, v3 Bl, float r, float skip, int id,
@@ -1217,7 +1278,7 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
             const bool take_ = !(eg_ > 0.0f);                                                                            \
             cur_t[r] = take_ ? (t_) : cur_t[r];                                                                          \
             cur_id[r] = take_ ? (id_) : cur_id[r];                                                                       \
-            chk = __builtin_fmaf(0.0f, cur_t[r], chk);                                                                   \
+            chk = __builtin_fmaf(0.0f, take_ ? (t_) : 0.0f, chk);   /* the accepted t only: cur_t is -inf for root-box misses (see face_fold_t) */ \
         }
         else if (GA && kind == OP_LEAF_VOLBOX) {   // constant_medium::hit volume.h:29-93 with a box boundary
 #pragma unroll
@@ -1228,24 +1289,67 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
                     asm volatile("; volbox ieee");
                     box_hit_shared(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
                     box_hit_shared(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
-                } else {
-                    asm volatile("; volbox fast");
+                    chk = __builtin_fmaf(0.0f, t1v, chk);   // a NaN boundary t: let the general sweep decide
+                    chk = __builtin_fmaf(0.0f, t2v, chk);
+                } else if (!PT_VOL_SHARED) {
+                    asm volatile("; volbox fast, two queries");
                     box_hit_fast(q0, q1, Al, Bl[r], -FLT_MAX, FLT_MAX, t1v, f1);
                     box_hit_fast(q0, q1, Al, Bl[r], (float)((double)t1v + 0.0001), FLT_MAX, t2v, f2);
+                    chk = __builtin_fmaf(0.0f, t1v, chk);
+                    chk = __builtin_fmaf(0.0f, t2v, chk);
+                } else {
+                    // Round 5: BOTH boundary queries of the medium (volume.h:38-40: boundary->hit(r, -FLT_MAX, FLT_MAX, rec1), then
+                    // boundary->hit(r, rec1.t + 0.0001, FLT_MAX, rec2)) from ONE evaluation of the box's six sides.  The two calls
+                    // compute the same six quotients and the same six hit points; they differ only in which sides the t range
+                    // lets through.  hittable_list::hit keeps the smallest accepted t (primitive.h:243-246, hittable_list.h:21-38), and
+                    // the medium wants the two t, not the sides: with tt[i] = the side's t where its hit point is inside the side's
+                    // bounds and +inf elsewhere, rec1.t = min tt and rec2.t = min { tt[i] : !(tt[i] < rec1.t + 0.0001) }.  A local
+                    // direction component that cancelled to exactly zero (rotated leaves only) would make a quotient infinite or NaN:
+                    // 0 * its refined reciprocal turns the tracker NaN and the wave repeats the query on the general sweep, so every
+                    // t here is finite and the sequential "t <= closest_so_far" fold IS the minimum.
+                    asm volatile("; volbox fast");
+                    float tt[6];
+#define VOL_AXIS(PLANE, DPL, X0, Z0, X1, Z1, N0, N1, OX, OZ, I0)                                                          \
+                    {                                                                                                    \
+                        float dx_, dpl_, dz_, ta_, tb_;                                                                  \
+                        rect_axes<PLANE>(Bl[r], dx_, dpl_, dz_);                                                         \
+                        const float rc_ = fdiv_rcp(dpl_);                                                                \
+                        if (rot) chk = __builtin_fmaf(0.0f, rc_, chk);                                                   \
+                        fdiv_q2_nofix((N0), (N1), dpl_, rc_, ta_, tb_);                                                  \
+                        const float xa_ = (OX) + ta_ * dx_, za_ = (OZ) + ta_ * dz_, xb_ = (OX) + tb_ * dx_, zb_ = (OZ) + tb_ * dz_; \
+                        tt[(I0)] = (side_excess((X0), (Z0), (X1), (Z1), xa_, za_) > 0.0f) ? INFINITY : ta_;              \
+                        tt[(I0) + 1] = (side_excess((X0), (Z0), (X1), (Z1), xb_, zb_) > 0.0f) ? INFINITY : tb_;          \
+                    }
+                    VOL_AXIS(0, z, q0[0], q0[1], q1[0], q1[1], q0[2] - Al.z, q1[2] - Al.z, Al.x, Al.y, 0)
+                    VOL_AXIS(2, x, q0[1], q0[2], q1[1], q1[2], q0[0] - Al.x, q1[0] - Al.x, Al.y, Al.z, 2)
+                    VOL_AXIS(1, y, q0[0], q0[2], q1[0], q1[2], q0[1] - Al.y, q1[1] - Al.y, Al.x, Al.z, 4)
+#undef VOL_AXIS
+                    const float m1 = fminf(fminf(fminf(tt[0], tt[1]), fminf(tt[2], tt[3])), fminf(tt[4], tt[5]));
+                    f1 = (m1 < INFINITY) ? 0 : -1;
+                    t1v = (m1 < INFINITY) ? m1 : FLT_MAX;                 // no side hit: closest_so_far stays t_max
+                    const float lo2 = (float)((double)t1v + 0.0001);
+                    float m2 = INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) m2 = fminf(m2, (tt[i] < lo2) ? INFINITY : tt[i]);
+                    f2 = (m2 < INFINITY) ? 0 : -1;
+                    t2v = (m2 < INFINITY) ? m2 : FLT_MAX;
                 }
                 bool hit = (f1 >= 0) && (f2 >= 0);
-                chk = __builtin_fmaf(0.0f, t1v, chk);   // a NaN boundary t: let the general sweep decide
-                chk = __builtin_fmaf(0.0f, t2v, chk);
                 t1v = (t1v < T_MIN) ? T_MIN : t1v;
                 t2v = (t2v > T_MAX) ? T_MAX : t2v;
                 hit = hit && !(t1v >= t2v);
                 t1v = (t1v < 0) ? 0.0f : t1v;
-                const float dlen = vlen(Bl[r]);
-                const float distance_inside = (t2v - t1v) * dlen;
-                const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
-                const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
-                hit = hit && (hit_distance < distance_inside);
-                const float tv = t1v + hit_distance / dlen;
+                float tv = 0.0f;
+                // the free-flight draw (volume.h:70) only where some ray of the wave crosses the medium at all: its result is used
+                // by no other lane, and in stream mode a draw that is not made costs its dimension nothing
+                if (!PT_VOL_LAZY_DRAW || __any(hit)) {
+                    const float dlen = vlen(Bl[r]);
+                    const float distance_inside = (t2v - t1v) * dlen;
+                    const float u = rndf(k0, k1, vol_dim_base[r] + (uint32_t)OPW(23));
+                    const float hit_distance = (-(1 / OPF(18))) * ptm_logf(u);
+                    hit = hit && (hit_distance < distance_inside);
+                    tv = t1v + hit_distance / dlen;
+                }
                 FOLD_GA(r, hit ? 0.0f : 1.0f, tv, op_id_base)
             }
         } else if (GA && kind == OP_LEAF_SPHERE) {   // sphere::hit primitive.h:64-95 (IEEE divisions: a = |Bl|^2 may leave the precondition)

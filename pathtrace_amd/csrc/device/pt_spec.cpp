@@ -154,7 +154,8 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
         for (auto &e : ev) envp.push_back(&e[0]);
         envp.push_back(nullptr);
         pid_t pid = 0;
-        if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, envp.data()) == 0) {
+        if (cancel && cancel->load()) { why = "the context was destroyed before its module was built"; ran = true; r.status = -1; r.log = why; }
+        else if (posix_spawn(&pid, exe.c_str(), nullptr, nullptr, argv, envp.data()) == 0) {
             if (child_pid) child_pid->store((int)pid);
             // wait for it, at most two minutes (a compilation takes 1.5 - 3 s): a helper that hangs is killed, not waited for;
             // a context destroyed meanwhile (cancel) kills it too
@@ -211,6 +212,8 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     const std::string key = table + flags + env.flags + env.pf + "|" + env.rtc_shared + "|" + env.cc + "|" + env.rtc_lib;
     Globals &g = G();
     std::lock_guard<std::mutex> lock(g.rtc_mutex);
+    // a context destroyed while its job waited for the compiler: nothing to build
+    if (cancel && cancel->load()) { log = "the context was destroyed before its module was built"; return nullptr; }
     if (!env.brk.empty()) { log = "PATHTRACE_HIP_SPEC_BREAK is set: the per-scene build fails on purpose (fallback test)"; return nullptr; }
     auto hit = g.cache.find(key);
     if (hit != g.cache.end()) return hit->second;
@@ -355,7 +358,9 @@ const char *spec_log(SpecJob *j) { return j ? j->log.c_str() : ""; }
 static std::string json_escape(const std::string &t)
 {
     std::string o;
-    for (char ch : t) { if (ch == '"' || ch == '\\') o += '\\'; if ((unsigned char)ch >= 32) o += ch; }
+    // ASCII only: a compiler log cut at 300 bytes may end inside a UTF-8 sequence (its quotes are U+2018 / U+2019), and the line
+    // must decode whatever it holds
+    for (char ch : t) { if (ch == '"' || ch == '\\') o += '\\'; if ((unsigned char)ch >= 32 && (unsigned char)ch < 127) o += ch; else if ((unsigned char)ch >= 127) o += '?'; }
     return o;
 }
 static std::string info_of(const CodeObject *obj, int status, const std::string &note)

@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]   # the BASELINE configs
 # beyond BASELINE: sphere lights + metal, dielectric, a room-filling volume
-EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
+EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2", "cornell_box_nested_fog"]   # the last: a medium inside a medium (volume.h:10)
 # checker / perlin textures, textured emitter and textured World::background
 TEXTURE_SCENES = ["cornell_box_image_light", "textured_room", "image_room"]
 ALL_SCENES = SCENES + EXTRA_SCENES + TEXTURE_SCENES

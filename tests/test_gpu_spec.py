@@ -27,7 +27,10 @@ def test_specialised_sweep_is_bit_exact_vs_oracle(oracle, scene, spec_sync):
     w, h, spp = 96, 54, 6
     sc = pt.Scene(scene_path(scene), w, h)
     r = pt.Renderer(sc, seed=5)
-    assert r.spec_status() == 1, pt.last_error()          # built inside pt_create, module loaded
+    if scene == "cornell_box_nested_fog":                  # a medium whose boundary is a medium runs the general sweep: no fast program
+        assert r.spec_status() == -1                       # to specialise, the generic kernels render
+    else:
+        assert r.spec_status() == 1, pt.last_error()      # built inside pt_create, module loaded
     fb = r.render(spp)
     ctr = r.counters()
     r.close()

@@ -177,6 +177,29 @@ scenes["cornell_box_with_volume2"] = {
     + [rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
 }
 
+# A medium whose boundary is a medium (volume.h:10: constant_medium takes ANY hittable as its boundary; the scene format's
+# "primitive" id of a volume may name an earlier volume, scene_parser.h:214-232): the outer medium's two boundary queries
+# are two scattering events of the inner one, each with a free-flight draw of its own, then the outer's own draw between
+# them.  One with a box as the innermost boundary (the short block's place), one with a sphere floating beside it.
+scenes["cornell_box_nested_fog"] = {
+    "camera": camera(-700.0),
+    "world": {"color": [0.05, 0.05, 0.08]},
+    "assets": [], "textures": [],
+    "materials": [lambertian("green", (0.12, 0.45, 0.15)), lambertian("red", (0.65, 0.05, 0.05)),
+                  lambertian("white", (0.73, 0.73, 0.73)), light_mat((1.0, 1.0, 1.0))],
+    "primitives": [
+        BASE_PRIMS[0],
+        {"id": "box", "type": "box", "size": [165, 165, 165]},
+        {"id": "fog_in", "type": "volume", "primitive": "box", "density": 0.02, "color": [0.9, 0.9, 0.9]},
+        {"id": "fog_out", "type": "volume", "primitive": "fog_in", "density": 0.01, "color": [0.7, 0.85, 1.0]},
+        {"id": "ball", "type": "sphere", "radius": 80, "material": {"id": "white"}},
+        {"id": "mist_in", "type": "volume", "primitive": "ball", "density": 0.03, "color": [0.9, 0.9, 0.9]},
+        {"id": "mist_out", "type": "volume", "primitive": "mist_in", "density": 0.02, "color": [1.0, 0.8, 0.6]},
+    ],
+    "instances": walls([{"skip": True, **ref("box", **SHORT_BOX_XF)}, ref("fog_out", **SHORT_BOX_XF)])
+    + [ref("mist_out", translate=[150.0, 380.0, 330.0]), rect_light(240, 230, (273, 554.0, 171)), SKIPPED_SPHERE],
+}
+
 # The reference's seventh scene, cornell_box_image_light.json.  Its "png" texture points at
 # assets/light_texture.png, which the reference repository does not contain, so the reference cannot load the file as
 # shipped; here that one texture entry carries the parser's own "skip" flag (scene_parser.h:265).  Nothing else refers to

@@ -30,7 +30,7 @@ from oracle import scene_params as sp  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 SCENES = ["cornell_box", "cornell_box_small_lights", "cornell_box_with_volume"]
 # scenes beyond the BASELINE configs: sphere lights + metal, dielectric, a room-filling volume
-EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2"]
+EXTRA_SCENES = ["light_test", "three_orbs", "cornell_box_with_volume2", "cornell_box_nested_fog"]   # the last: a medium whose boundary is a medium
 # checker / perlin textures, textured emitter, textured World::background (scenes/ + tools/author_scenes.py)
 TEXTURE_SCENES = ["cornell_box_image_light", "textured_room", "image_room"]
 EXTRA_SCENES = EXTRA_SCENES + TEXTURE_SCENES
