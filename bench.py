@@ -755,7 +755,7 @@ def main():
                        "framebuffer_sum": fb_sum,
                        "partition": "whole frame" if n == 1 else (f"128x128 tiles, spiral order, " + ("tile k -> rank k mod N" if os.environ.get("PT_BENCH_ROUND_ROBIN") == "1" else "cost-balanced ownership (LPT over per-tile ray counts)") + "; 1 collective"),
                        "partition_setup_ms": round(setup_ms, 1),
-                       "sweep": sweep_label(spec_state, spec_info)["sweep"] + ((" of k_extend and k_connect (hiprtc at pt_create)" if os.environ.get("PATHTRACE_HIP_SPEC_CONNECT", "1")[:1] != "0" else " of k_extend (hiprtc at pt_create), generic k_connect") if spec_state == 1 else ""),
+                       "sweep": sweep_label(spec_state, spec_info)["sweep"] + ((" of k_extend and k_connect (hiprtc at pt_create)" if "extend-only" not in os.environ.get("PATHTRACE_HIP_SPEC", "") else " of k_extend (hiprtc at pt_create), generic k_connect") if spec_state == 1 else ""),
                        "module": sweep_label(spec_state, spec_info),
                        "exchange": None if n == 1 else ("gather of owned tiles: %d bytes to rank 0" % exchange.bytes_moved() if exchange else "sum-reduce of whole frames"),
                        "knobs": knobs},

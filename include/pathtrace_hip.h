@@ -25,6 +25,27 @@ extern "C" {
 
 #define PT_ABI_VERSION 6
 
+/* ---- environment variables the library reads (all of them; none is needed for normal use, none changes a pixel) --------------
+ *   PATHTRACE_HIP_DEVICES       pth_main / HipWavefront: "0,1,.." or "all" -- the devices that render (default: config.json's
+ *                               `threads`, capped by the devices present); an ordinal may repeat ("0,0": a one-GPU rehearsal)
+ *   PATHTRACE_HIP_LANES         1..4 stream lanes per context (default 3); 1 = every kernel alone on the chip (profiling)
+ *   PATHTRACE_HIP_PLAN          comma list: caller (every render call is one batch as far as the slots allow: probing other launch
+ *                               plans), max=<paths> (cap of the library's own sizing, default PT_PLAN_MAX_PATHS), seg=<slots>
+ *                               (queue segment size, default 4096, a multiple of 256)
+ *   PATHTRACE_HIP_SPEC          per-scene build of the traversal kernels: async (default) | sync | off, optionally ",extend-only"
+ *                               (shadow rays stay on the generic k_connect)
+ *   PATHTRACE_HIP_SPEC_FLAGS    more compiler options for that build (-DPT_CONNECT_WAVES=4, -mllvm ...)
+ *   PATHTRACE_HIP_SPEC_CC       its compile helper (default: pt_spec_cc beside the library); "in-process" = no helper
+ *   PATHTRACE_HIP_SPEC_DUMP     file to write the module's code object to
+ *   PATHTRACE_HIP_SPEC_BREAK    make the build fail on purpose (the fallback onto the generic kernels, tested)
+ *   PATHTRACE_HIP_TRAVERSAL     comma list forcing a traversal form: general (no fast sweep), walk (per-lane walk also for small
+ *                               scenes), sweep (never the walk), tree (no flat program) -- the tests hold the forms to each other
+ *   PATHTRACE_HIP_SHADE         comma list: sort | nosort (k_shade's chunk sort on / off), nostage (every hit gets a shadow record)
+ *   PATHTRACE_HIP_MULTI         comma list for pt_multi: roundrobin (tile k -> device k mod n), rccl (ncclReduce of whole frames)
+ *   PATHTRACE_HIP_TRACE_LAUNCH  one stream synchronisation and one stderr line per launch (names the kernel in front of a fault)
+ * Everything else that used to be a run-time knob (grid size, segment merging, rays per sweep, ...) is a -D of the build:
+ * `python -m pathtrace_amd.build --variant NAME -DPT_...`, loaded by the Python binding through PATHTRACE_HIP_LIB. */
+
 /* material.h:27-277 */
 enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
 /* primitive.h:27-256, volume.h:7-93 */
@@ -277,11 +298,11 @@ int pt_trace_rays(pt_ctx *ctx, int64_t n, int32_t rays_per_origin, const float *
 /* ---- multi-GPU in one process ------------------------------------------------------------
  * One context per listed device (an ordinal may repeat: two contexts on one GPU rehearse the path on a one-GPU box).
  * The film is cut into block_w x block_h tiles in NaiveSpiral order (queue.h:68-127) and every tile is owned by one
- * device (cost-balanced over measured per-tile ray counts; PATHTRACE_HIP_ROUND_ROBIN=1: tile k -> device k mod n);
+ * device (cost-balanced over measured per-tile ray counts; PATHTRACE_HIP_MULTI=roundrobin: tile k -> device k mod n);
  * pt_multi_render_async enqueues each device's tiles as wavefront batches and returns, there is no communication while
  * rendering, and reading the framebuffer sums the per-device framebuffers into the first device -- every peer sends only
  * the pixels of the tiles it owns (packed, one device-to-device copy per peer over its own link, added on the root), or
- * one RCCL ncclReduce per device (PATHTRACE_HIP_MULTI_RCCL=1).  The result is the
+ * one RCCL ncclReduce per device (PATHTRACE_HIP_MULTI=rccl).  The result is the
  * single-device image bit for bit.  Replaces the thread fan-out of Tiled::start_render (renderer.h:553-603). */
 typedef struct pt_multi pt_multi;
 pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config *config, int32_t n_devices, const int32_t *devices,

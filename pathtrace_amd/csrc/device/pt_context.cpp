@@ -39,6 +39,24 @@ int launch_grid_max();
 using namespace ptd;
 
 static thread_local std::string g_err;
+// An environment variable that holds a comma-separated list of tokens (PATHTRACE_HIP_PLAN, _SPEC, _TRAVERSAL, _SHADE: the table in
+// include/pathtrace_hip.h): is `token` one of them?  `value` (optional) receives what follows "token=".
+static bool env_token(const char *var, const char *token, std::string *value = nullptr)
+{
+    const char *e = getenv(var);
+    if (!e) return false;
+    const size_t tl = strlen(token);
+    for (const char *p = e; *p;) {
+        const char *q = strchr(p, ',');
+        const size_t n = q ? (size_t)(q - p) : strlen(p);
+        if (n >= tl && !strncmp(p, token, tl) && (n == tl || p[tl] == '=')) {
+            if (value) *value = (n > tl) ? std::string(p + tl + 1, n - tl - 1) : std::string();
+            return true;
+        }
+        p += n + (q ? 1 : 0);
+    }
+    return false;
+}
 static void set_err(const char *fmt, ...)
 {
     char buf[1024];
@@ -61,7 +79,7 @@ extern "C" const char *pt_last_error(void) { return g_err.c_str(); }
 // Segments stop merging at this many: every wave of k_shade reserves its output ranges with returning atomics on the output
 // segment's two counters, and with a handful of segments left (32 at bounce 9 of a 66 M-path batch) those serialise: k_shade's
 // launches of bounces 7 - 9 took 228 / 204 / 219 us, with 507 segments kept 174 / 132 / 108.
-// PATHTRACE_HIP_MERGE_MIN overrides it for measurements.
+// (A build-time constant: -DPT_MERGE_MIN_SEGMENTS=... for measurements; floors of 256 - 1024 are equal, 0 and 4096 worse.)
 #ifndef PT_MERGE_MIN_SEGMENTS
 #define PT_MERGE_MIN_SEGMENTS 512
 #endif
@@ -397,7 +415,7 @@ static int build_program(const pt_scene_desc *sc, HostProgram &hp)
     // needs neither them nor the pushes), ENTER's skip target re-indexed; stored behind the general program
     const int n_general = (int)ops.size() - 1;
     // flat mode (pt_device.h DScene::chains): few instances, shallow tree -> leaves only, ancestors checked afterwards
-    const bool flat = sc->n_instances <= PT_FLAT_MAX_INSTANCES && max_depth <= PT_MAX_STACK && !getenv("PATHTRACE_HIP_NO_FLAT");
+    const bool flat = sc->n_instances <= PT_FLAT_MAX_INSTANCES && max_depth <= PT_MAX_STACK && !env_token("PATHTRACE_HIP_TRAVERSAL", "tree");
     // (the root's ENTER stays: a wave of camera rays that miss the scene's box leaves the program after one op)
     auto in_fast = [&](const DOp &o) { return o.kind != OP_COMBINE && !(flat && o.kind == OP_ENTER && &o != &ops[0]); };
     std::vector<int> fast_index(n_general + 1, 0);
@@ -443,15 +461,15 @@ static int build_program(const pt_scene_desc *sc, HostProgram &hp)
     for (const DOp &op : ops) hp.geom_all |= (op.kind >= OP_LEAF_SPHERE);
     {   // precondition of the sweep's unscaled division (pt_fdiv.h, pt_kernels.hip world_hit_fast): a leaf's linear part is
         // zero or within [2^-44, 2^13] per entry (float residues of a rotation by a multiple of pi/2 are ~1e-8), its
-        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  PATHTRACE_HIP_NO_FASTDIV=1 (an
-        // A/B measurement knob) or an unordered / non-finite node box send the whole scene to the general sweep.
+        // translation zero or within [2^-44, 2^20], its bounds zero or within [2^-20, 2^20].  PATHTRACE_HIP_TRAVERSAL=general (the
+        // tests hold the sweeps to each other with it) or an unordered / non-finite node box send the whole scene to the general sweep.
         auto in_range = [](float x, int lo, int hi) {
             uint32_t u;
             memcpy(&u, &x, 4);
             u &= 0x7fffffffu;
             return u == 0u || (u - ((uint32_t)(127 + lo) << 23)) <= ((uint32_t)(hi - lo) << 23);
         };
-        hp.tame = getenv("PATHTRACE_HIP_NO_FASTDIV") ? 0 : 1;
+        hp.tame = env_token("PATHTRACE_HIP_TRAVERSAL", "general") ? 0 : 1;
         for (const DOp &op : ops) if (op.kind == OP_LEAF_VOLVOL) hp.tame = 0;   // a medium in a medium: the general sweep carries it
         for (int oi = 0; oi < (int)ops.size(); oi++) {
             DOp &op = ops[oi];
@@ -728,8 +746,8 @@ static int build_scene(pt_ctx *c, const pt_scene_desc *sc)
             wn[2 * i + 1] = make_float4(n.bbox[3], n.bbox[4], n.bbox[5], rf);
         }
         if (!ok) { set_err("pt_create: a bvh leaf without an op"); return -1; }
-        S.walk = (sc->n_instances > PT_WALK_MIN_INSTANCES && S.tame && !getenv("PATHTRACE_HIP_NO_WALK")) ? 1 : 0;
-        if (getenv("PATHTRACE_HIP_FORCE_WALK") && S.tame) S.walk = 1;   // measurement / test knob: walk small scenes too
+        S.walk = (sc->n_instances > PT_WALK_MIN_INSTANCES && S.tame && !env_token("PATHTRACE_HIP_TRAVERSAL", "sweep")) ? 1 : 0;
+        if (env_token("PATHTRACE_HIP_TRAVERSAL", "walk") && S.tame) S.walk = 1;   // measurement / test knob: walk small scenes too
         if (dev_upload(c, &S.wnodes, wn)) return -1;
     }
     S.n_lights = (int)lights.size(); S.n_vol = nvol;
@@ -845,7 +863,7 @@ static int size_streams(pt_ctx *c, int64_t want)
         c->plan.grown++;
     }
     int seg = c->seg_cap;
-    if (const char *e = getenv("PATHTRACE_HIP_SEG")) { int v = atoi(e); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) seg = v; }
+    { std::string sv; if (env_token("PATHTRACE_HIP_PLAN", "seg", &sv)) { const int v = atoi(sv.c_str()); if (v >= 256 && v <= (1 << 20) && v % 256 == 0) seg = v; } }
     c->seg_cap = seg;
     c->n_seg_max = (int)((want + c->seg_cap - 1) / c->seg_cap);
     c->P = (int64_t)c->n_seg_max * c->seg_cap;
@@ -884,7 +902,7 @@ static int64_t plan_slots(pt_ctx *c, int64_t pixels, int samples)
 {
     size_t hfree = 0, htotal = 0;
     int64_t cap = PT_PLAN_MAX_PATHS;
-    if (const char *e = getenv("PATHTRACE_HIP_PLAN_MAX_PATHS")) { const long long v = atoll(e); if (v >= 64) cap = v; }   // measurement knob
+    { std::string mv; if (env_token("PATHTRACE_HIP_PLAN", "max", &mv)) { const long long v = atoll(mv.c_str()); if (v >= 64) cap = v; } }   // measurement knob: PATHTRACE_HIP_PLAN=max=<paths>
     if (hipMemGetInfo(&hfree, &htotal) == hipSuccess) {
         const double avail = ((double)hfree + (double)c->plan.stream_bytes) * PT_PLAN_HBM_FRACTION;
         const int64_t by_mem = (int64_t)(avail / ((double)slot_bytes(c) * c->n_lanes_alloc)) - 2 * (int64_t)(c->seg_cap + 256);
@@ -956,14 +974,12 @@ extern "C" pt_ctx *pt_create(const pt_scene_desc *scene, const pt_config *config
     if (!c->auto_size && size_streams(c, c->cfg.max_paths_in_flight)) return fail();
     {   // the per-scene build of the sweep: PATHTRACE_HIP_SPEC = async (default: built on a thread of its own, used when ready),
         // sync (built before pt_create returns), off.  Scenes without a fast program keep the generic kernels.
-        const char *mode = getenv("PATHTRACE_HIP_SPEC");
-        const bool off = mode && !strcmp(mode, "off");
+        const bool off = env_token("PATHTRACE_HIP_SPEC", "off");
         std::string table;
         if (!off && !c->S.walk && spec_header_text(scene, table) > 0) {
             const int L = c->cfg.light_samples;
-            int spec_nr = (L % 2 == 0) ? 2 : 1;   // rays per sweep of the module's k_connect; PATHTRACE_HIP_SPEC_NR=4 for measurements
-            if (const char *e = getenv("PATHTRACE_HIP_SPEC_NR")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && L % v == 0) spec_nr = v; }
-            c->spec = spec_start(table, c->S.geom_all != 0, c->S.textured != 0, spec_nr, c->device, mode && !strcmp(mode, "sync"));
+            const int spec_nr = (L % 2 == 0) ? 2 : 1;   // rays per sweep of the module's k_connect (4: measured slower, LOGBOOK)
+            c->spec = spec_start(table, c->S.geom_all != 0, c->S.textured != 0, spec_nr, c->device, env_token("PATHTRACE_HIP_SPEC", "sync"));
         }
         g_err.clear();   // spec_header_text leaves a message for scenes it does not serve: not an error of pt_create
     }
@@ -1049,11 +1065,10 @@ struct Timer {
 
 // Multiplier of the order in which the persistent workgroups visit the n segments of a queue (pt_kernels.hip ChunkWalk):
 // ~ n / golden ratio, the stride whose multiples mod n are the most evenly spread, made coprime to n so that k -> k * mul
-// mod n is a permutation.  PATHTRACE_HIP_NO_PERM=1 (A/B knob): queue order.
+// mod n is a permutation.  (Queue order, the A/B of round 3: rank times of an 8-way partition +-7 % instead of +-2.5 %.)
 static int seg_perm(int n)
 {
-    static const bool off = getenv("PATHTRACE_HIP_NO_PERM") != nullptr;
-    if (off || n < 16 || n >= 65536) return 1;   // the kernels form k * mul in 32 bits
+    if (n < 16 || n >= 65536) return 1;   // the kernels form k * mul in 32 bits
     long long m = llround((double)n * 0.6180339887498949);
     auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
     while (gcd(m, n) != 1) m++;
@@ -1095,9 +1110,7 @@ static int run_batch(pt_ctx *c, const DBatch &b)
     DBatch bb = b;
     for (int bounce = 0; bounce < S.max_bounces; bounce++) {
         // segments merge pairwise from one bounce to the next (pt_device.h DBatch) until one is left
-        static const bool no_merge = getenv("PATHTRACE_HIP_NO_MERGE") != nullptr;
-        static const int merge_min = getenv("PATHTRACE_HIP_MERGE_MIN") ? atoi(getenv("PATHTRACE_HIP_MERGE_MIN")) : PT_MERGE_MIN_SEGMENTS;
-        if (bb.n_seg > 1 && bb.n_seg > merge_min && !no_merge) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
+        if (bb.n_seg > 1 && bb.n_seg > PT_MERGE_MIN_SEGMENTS) { bb.n_seg_out = (bb.n_seg + 1) / 2; bb.seg_cap_out = bb.seg_cap * 2; }
         else { bb.n_seg_out = bb.n_seg; bb.seg_cap_out = bb.seg_cap; }
         bb.perm = seg_perm(bb.n_seg); bb.perm_out = seg_perm(bb.n_seg_out);
         { Timer t(c, PT_K_EXTEND, sm); launch_extend(S, st, bb, qi, bounce, sm, spec); }
@@ -1150,7 +1163,7 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
     // the launch plan (plan_batches): equal batches, as few as the slots allow, at least two, a multiple of the lanes
     // (PATHTRACE_HIP_PLAN=caller, a measurement knob: the caller's calls ARE the batches, cut only where the slots force it --
     // the rule up to ABI v5 -- so that tools/plan_probe.py can time plans other than the library's)
-    static const bool caller_plan = getenv("PATHTRACE_HIP_PLAN") && !strcmp(getenv("PATHTRACE_HIP_PLAN"), "caller");
+    static const bool caller_plan = env_token("PATHTRACE_HIP_PLAN", "caller");
     int n_batches = 0;
     int ns_plan = plan_batches(npix, spp_end - spp_begin, c->P, c->n_lanes, &n_batches);
     if (caller_plan) { ns_plan = (int)std::max<int64_t>(1, c->P / npix); n_batches = (spp_end - spp_begin + ns_plan - 1) / ns_plan; }
@@ -1170,8 +1183,8 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         // {g * seg_cap * 16 B}.  When a sample's pixels are a multiple of 2^16 -- e.g. 16 tiles of 128 x 128 -- the live
         // segments (the pixels over the scene) repeat with a power-of-two period from sample to sample and their addresses
         // fall on a fraction of the HBM channels: measured 45.5 against 28.3 ms for 2^18 pixels x 54 spp.  One more chunk
-        // per segment breaks the period.  (PATHTRACE_HIP_SEG fixes the size for measurements.)
-        const bool seg_forced = getenv("PATHTRACE_HIP_SEG") != nullptr;
+        // per segment breaks the period.  (PATHTRACE_HIP_PLAN=seg=N fixes the size for measurements and tests.)
+        const bool seg_forced = env_token("PATHTRACE_HIP_PLAN", "seg");
         b.seg_cap = (npix % 65536 == 0 && !seg_forced) ? c->seg_cap + 256 : c->seg_cap;
         b.n_paths = npix * ns;
         b.n_seg = (int)((b.n_paths + b.seg_cap - 1) / b.seg_cap);
@@ -1181,11 +1194,11 @@ static int render_group(pt_ctx *c, const std::vector<DTile> &bands, const std::v
         if ((int64_t)b.n_seg * b.seg_cap > c->P_phys || b.n_seg > c->n_seg_max) { set_err("pt_render_tiles_async: internal error: %d segments of %d slots exceed the streams", b.n_seg, b.seg_cap); return -1; }
         // the chunk sort of k_shade costs two workgroup barriers per chunk; measured it pays where a hit is
         // expensive and uneven -- textures, or more than two lights (per-lane light records, sphere lights) -- and not on
-        // the one- and two-light Cornell scenes.  PATHTRACE_HIP_SORT=1 / PATHTRACE_HIP_NO_SORT=1 force it for measurements.
+        // the one- and two-light Cornell scenes.  PATHTRACE_HIP_SHADE=sort / nosort force it for measurements and tests.
         b.sort_shade = (c->S.textured || c->S.n_lights > 2) ? 1 : 0;
-        if (getenv("PATHTRACE_HIP_SORT")) b.sort_shade = 1;
-        if (getenv("PATHTRACE_HIP_NO_SORT")) b.sort_shade = 0;
-        b.stage_shadow = (c->S.light_samples >= 1 && c->S.light_samples <= PT_STAGE_MAX_SAMPLES && !getenv("PATHTRACE_HIP_NO_STAGE")) ? 1 : 0;
+        if (env_token("PATHTRACE_HIP_SHADE", "sort")) b.sort_shade = 1;
+        if (env_token("PATHTRACE_HIP_SHADE", "nosort")) b.sort_shade = 0;
+        b.stage_shadow = (c->S.light_samples >= 1 && c->S.light_samples <= PT_STAGE_MAX_SAMPLES && !env_token("PATHTRACE_HIP_SHADE", "nostage")) ? 1 : 0;
         if (run_batch(c, b)) return -1;
         s += ns;
     }

@@ -38,6 +38,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #endif
 
 #include "pt_device.h"
@@ -2852,12 +2853,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace(DScene S, const DOp *__restr
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 // at most 4096 workgroups per launch (256 CUs x 8 resident x 2: measured better balanced than 2048), few enough to dispatch quickly
-static int g_grid_max = 0;
-static int persistent_grid(long long chunks)
-{
-    if (!g_grid_max) { const char *e = getenv("PATHTRACE_HIP_GRID"); g_grid_max = e ? atoi(e) : 4096; if (g_grid_max < 1) g_grid_max = 4096; }
-    return (int)(chunks < g_grid_max ? chunks : g_grid_max);
-}
+#ifndef PT_GRID_MAX
+#define PT_GRID_MAX 4096   // (-DPT_GRID_MAX=... for measurements: 2048 is less balanced, 8192 dispatches more slowly)
+#endif
+static int persistent_grid(long long chunks) { return (int)(chunks < PT_GRID_MAX ? chunks : PT_GRID_MAX); }
 void launch_generate(const DScene &S, const DStreams &st, const DBatch &b, hipStream_t s)
 {
     hipLaunchKernelGGL(k_generate, dim3(b.n_seg), dim3(PT_BLOCK), 0, s, S, st, b);
@@ -2897,14 +2896,12 @@ void launch_connect(const DScene &S, const DStreams &st, const DBatch &b, int bo
     const int L = S.light_samples;
     // rays of one hit traversed together: 2 when light_samples is even, else 1.  Measured on cornell_box 1080p: 2 rays
     // (80 VGPRs, 6 waves/SIMD) beat 4 rays (112 VGPRs, 4 waves/SIMD: more sharing, less latency hiding) and 1 ray.
-    static const int force = getenv("PATHTRACE_HIP_CONNECT_NR") ? atoi(getenv("PATHTRACE_HIP_CONNECT_NR")) : 0;
     int nr = (L % 2 == 0) ? 2 : 1;
-    if (force == 1 || force == 2 || force == 4) nr = (L % force == 0) ? force : nr;
     if (S.walk) nr = 1;   // the walk takes its rays one at a time
     // The module's k_connect (straight-line sweep, 5 waves per SIMD) is worth 3 - 4 % of this kernel -- two rays per sweep already
-    // share the op fetch of the generic loop.  PATHTRACE_HIP_SPEC_CONNECT=0 keeps shadow rays on the generic kernel (the A/B).
-    const char *sc_env = getenv("PATHTRACE_HIP_SPEC_CONNECT");   // read per launch: the tests switch it
-    const bool spec_connect = !(sc_env && sc_env[0] == '0');
+    // share the op fetch of the generic loop.  PATHTRACE_HIP_SPEC=...,extend-only keeps shadow rays on the generic kernel (the A/B).
+    const char *sc_env = getenv("PATHTRACE_HIP_SPEC");   // read per launch: the tests switch it
+    const bool spec_connect = !(sc_env && strstr(sc_env, "extend-only"));
     if (!spec_connect) spec = nullptr;
     if (spec && !S.walk && L % spec_connect_nr(spec) == 0) nr = spec_connect_nr(spec);
     const size_t lds = st.gstack ? 0 : (size_t)S.stack_depth * (nr ? nr : 1) * PT_BLOCK * sizeof(float2);

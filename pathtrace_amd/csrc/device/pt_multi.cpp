@@ -13,7 +13,7 @@
 // over that peer's own xGMI link -- and one add kernel per peer scatters them into the root's sum (ownership is disjoint,
 // so the adds touch disjoint pixels and run concurrently).  Bytes moved = the pixels the peers own x 16: at 4K on 8
 // devices 7/8 x 133 MB = 116 MB in all instead of 7 whole frames.  It also works when one device is listed twice.
-// PATHTRACE_HIP_MULTI_RCCL=1: one RCCL ncclReduce per device in a group instead (librccl.so is loaded on demand, the
+// PATHTRACE_HIP_MULTI=rccl: one RCCL ncclReduce per device in a group instead (librccl.so is loaded on demand, the
 // library does not link it).
 #include <hip/hip_runtime.h>
 
@@ -181,7 +181,8 @@ extern "C" pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config
     const int n_tiles = pth_spiral_tiles(m->w, m->h, block_w, block_h, nullptr, 0);
     std::vector<int32_t> tiles((size_t)n_tiles * 4);
     pth_spiral_tiles(m->w, m->h, block_w, block_h, tiles.data(), n_tiles);
-    if (n_devices == 1 || getenv("PATHTRACE_HIP_ROUND_ROBIN")) {
+    const char *menv = getenv("PATHTRACE_HIP_MULTI");   // comma list: roundrobin (tile k -> device k mod n), rccl (ncclReduce of whole frames)
+    if (n_devices == 1 || (menv && strstr(menv, "roundrobin"))) {
         m->owner.resize(n_tiles);
         for (int k = 0; k < n_tiles; k++) m->owner[k] = k % n_devices;
     } else {
@@ -241,11 +242,11 @@ extern "C" pt_multi *pt_multi_create(const pt_scene_desc *scene, const pt_config
         if (!ok) { merr("pt_multi_create: exchange buffers for device %d: %s", m->dev[i], hipGetErrorString(hipGetLastError())); return fail(); }
     }
     if (hipSetDevice(m->dev[0]) != hipSuccess) { merr("pt_multi_create: hipSetDevice(%d)", m->dev[0]); return fail(); }
-    if (getenv("PATHTRACE_HIP_MULTI_RCCL")) {
+    if (menv && strstr(menv, "rccl")) {
         bool distinct = true;
         for (int i = 0; i < n_devices; i++)
             for (int j = 0; j < i; j++) distinct = distinct && m->dev[i] != m->dev[j];
-        if (!distinct) { merr("pt_multi_create: PATHTRACE_HIP_MULTI_RCCL needs distinct devices"); return fail(); }
+        if (!distinct) { merr("pt_multi_create: PATHTRACE_HIP_MULTI=rccl needs distinct devices"); return fail(); }
         if (!m->rccl.load()) { merr("pt_multi_create: librccl.so could not be loaded"); return fail(); }
         m->comms.assign(n_devices, nullptr);
         const int rc = m->rccl.CommInitAll(m->comms.data(), n_devices, m->dev.data());

@@ -86,14 +86,13 @@ Globals &G() { static Globals *g = new Globals(); return *g; }
 // Every environment knob of the build, read ONCE on the thread that asks for the build (spec_start / spec_build_check): the
 // worker thread must not call getenv while the host thread may call setenv (Python's os.environ, a test's monkeypatch).
 struct SpecEnv {
-    std::string waves, generic, flags, pf, brk, dump, cc, rtc_shared, rtc_lib, tmpdir, path;
+    std::string flags, brk, dump, cc, tmpdir, path;   // cc = "in-process": no helper, whatever libhiprtc the process resolves (the A/B of round 4)
     static std::string get(const char *n) { const char *v = getenv(n); return v ? v : ""; }
     static SpecEnv snapshot()
     {
         SpecEnv e;
-        e.waves = get("PATHTRACE_HIP_SPEC_WAVES"); e.generic = get("PATHTRACE_HIP_SPEC_GENERIC"); e.flags = get("PATHTRACE_HIP_SPEC_FLAGS");
-        e.pf = get("PATHTRACE_HIP_SPEC_PF"); e.brk = get("PATHTRACE_HIP_SPEC_BREAK"); e.dump = get("PATHTRACE_HIP_SPEC_DUMP");
-        e.cc = get("PATHTRACE_HIP_SPEC_CC"); e.rtc_shared = get("PATHTRACE_HIP_RTC_SHARED"); e.rtc_lib = get("PATHTRACE_HIP_RTC_LIB");
+        e.flags = get("PATHTRACE_HIP_SPEC_FLAGS"); e.brk = get("PATHTRACE_HIP_SPEC_BREAK"); e.dump = get("PATHTRACE_HIP_SPEC_DUMP");
+        e.cc = get("PATHTRACE_HIP_SPEC_CC");
         e.tmpdir = get("TMPDIR"); e.path = get("PATH");
         return e;
     }
@@ -149,7 +148,6 @@ bool compile_in_child(const ptrtc::Request &q, ptrtc::Result &r, std::string &wh
         const std::string libdir = rocm_lib_dir();
         std::vector<std::string> ev = {"PATH=" + (env.path.empty() ? std::string("/usr/bin:/bin") : env.path), "TMPDIR=" + tmp,
                                        "LD_LIBRARY_PATH=" + libdir, "PT_SPEC_ROCM_LIB_DIR=" + libdir};
-        if (!env.rtc_lib.empty()) ev.push_back("PATHTRACE_HIP_RTC_LIB=" + env.rtc_lib);
         std::vector<char *> envp;
         for (auto &e : ev) envp.push_back(&e[0]);
         envp.push_back(nullptr);
@@ -207,9 +205,8 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
                                            std::atomic<int> *child_pid = nullptr, const std::atomic<bool> *cancel = nullptr)
 {
     char flags[256];
-    snprintf(flags, sizeof flags, "ga%d tex%d nr%d w%s g%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr, env.waves.empty() ? "5" : env.waves.c_str(),
-             env.generic.empty() ? 0 : 1);
-    const std::string key = table + flags + env.flags + env.pf + "|" + env.rtc_shared + "|" + env.cc + "|" + env.rtc_lib;
+    snprintf(flags, sizeof flags, "ga%d tex%d nr%d", geom_all ? 1 : 0, textured ? 1 : 0, connect_nr);
+    const std::string key = table + flags + env.flags + "|" + env.cc;
     Globals &g = G();
     std::lock_guard<std::mutex> lock(g.rtc_mutex);
     // a context destroyed while its job waited for the compiler: nothing to build
@@ -218,9 +215,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     auto hit = g.cache.find(key);
     if (hit != g.cache.end()) return hit->second;
     ptrtc::Request q;
-    // PATHTRACE_HIP_SPEC_GENERIC (measurement): the module holds the GENERIC kernels -- the library's own code through the module path
-    q.top = !env.generic.empty() ? "#define PT_SPEC_BUILD 1\n#include \"pt_kernels.hip\"\n"
-                                 : "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
+    q.top = "#define PT_SPEC_BUILD 1\n#define PT_SPEC_HEADER \"pt_spec_table.h\"\n#include \"pt_kernels.hip\"\n";
     q.top_name = "pt_spec_top.hip";
     q.headers = {{"pt_kernels.hip", kSrcKernels}, {"pt_device.h", kSrcDevice}, {"pt_fdiv.h", kSrcFdiv}, {"pt_spec_table.h", table}};
     const char *ga = geom_all ? "true" : "false", *tex = textured ? "true" : "false";
@@ -232,8 +227,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     // the product's flags (pathtrace_amd/build.py): no FMA contraction, IEEE division and square root; the specialised k_connect
     // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17) and without the early radiance request, which at this
     // register budget is spilled the moment it arrives
-    const char *waves = "-DPT_CONNECT_WAVES=5";
-    if (env.waves == "4") waves = "-DPT_CONNECT_WAVES=4"; else if (env.waves == "6") waves = "-DPT_CONNECT_WAVES=6";
+    const char *waves = "-DPT_CONNECT_WAVES=5";   // (4 and 6 measured in round 3: PATHTRACE_HIP_SPEC_FLAGS carries such options for an A/B)
     // -pragma-unroll-threshold: the sweep's op loop must unroll COMPLETELY for the table to fold into the code (kind, shapes and
     // constants are only compile-time values per unrolled iteration).  LLVM sizes the unrolled loop before it folds the per-kind
     // dispatch away -- every body of every leaf kind times PT_SPEC_N -- and past 16384 it quietly keeps a run-time loop that
@@ -242,7 +236,8 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     // (the option may occur once: PATHTRACE_HIP_SPEC_FLAGS that bring their own replace it -- the negative control of
     // tests/test_spec_build.py builds with a low threshold to see the check for a surviving table trip)
     if (env.flags.find("pragma-unroll-threshold") == std::string::npos) { q.opts.push_back("-mllvm"); q.opts.push_back("-pragma-unroll-threshold=4000000"); }
-    if (env.generic.empty()) { q.opts.push_back(waves); q.opts.push_back(env.pf == "1" ? "-DPT_CONNECT_PREFETCH=1" : (env.pf == "2" ? "-DPT_CONNECT_PREFETCH=2" : "-DPT_CONNECT_PREFETCH=0")); }
+    if (env.flags.find("PT_CONNECT_WAVES") == std::string::npos) q.opts.push_back(waves);
+    if (env.flags.find("PT_CONNECT_PREFETCH") == std::string::npos) q.opts.push_back("-DPT_CONNECT_PREFETCH=0");
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
     const std::string &extra = env.flags;   // measurement: more compiler options, space separated
     for (size_t i = 0; i < extra.size();) {
@@ -254,8 +249,8 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     ptrtc::Result r;
     std::string why;
     bool by_helper = true;
-    // PATHTRACE_HIP_RTC_SHARED=1 (the A/B): compile in-process with whatever libhiprtc the process resolves
-    if (!env.rtc_shared.empty() || !compile_in_child(q, r, why, env, child_pid, cancel)) {
+    // PATHTRACE_HIP_SPEC_CC=in-process (the A/B): compile in-process with whatever libhiprtc the process resolves
+    if (env.cc == "in-process" || !compile_in_child(q, r, why, env, child_pid, cancel)) {
         by_helper = false;
         const std::string dir = rocm_lib_dir();
         if (!g.rtc.load({dir + "/libhiprtc.so", "libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"})) { log = "no compiler: " + (why.empty() ? std::string() : why + "; ") + "libhiprtc.so could not be loaded"; return nullptr; }
@@ -391,25 +386,8 @@ void spec_destroy(SpecJob *j)
     delete j;
 }
 
-static int launch_(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args);
 static int launch(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args)
 {
-    static const bool timed = getenv("PATHTRACE_HIP_SPEC_TIME") != nullptr;   // measurement: host time spent inside the module launch call
-    if (!timed) return launch_(f, grid, lds, s, args);
-    static double total_us = 0.0, max_us = 0.0;
-    static long calls = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int rc = launch_(f, grid, lds, s, args);
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    total_us += us; calls++; if (us > max_us) max_us = us;
-    if (calls % 200 == 0) fprintf(stderr, "[pt spec] %ld module launches, mean %.1f us, max %.1f us inside the call\n", calls, total_us / calls, max_us);
-    return rc;
-}
-static int launch_(hipFunction_t f, int grid, size_t lds, hipStream_t s, void **args)
-{
-    static const char *how = getenv("PATHTRACE_HIP_SPEC_LAUNCH");
-    if (how && !strcmp(how, "ext"))
-        return hipExtModuleLaunchKernel(f, (unsigned)grid * 256u, 1, 1, 256, 1, 1, lds, s, args, nullptr, nullptr, nullptr, 0) == hipSuccess ? 0 : -1;
     return hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, s, args, nullptr) == hipSuccess ? 0 : -1;
 }
 

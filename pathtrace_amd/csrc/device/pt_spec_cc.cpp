@@ -1,5 +1,5 @@
 // pt_spec_cc REQUEST RESULT -- the per-scene build's compiler process (pt_spec.cpp starts it, pathtrace_amd/build.py builds it).
-// It loads THIS toolchain's libhiprtc (the directory it was built against, or PATHTRACE_HIP_RTC_LIB) in a process that holds
+// It loads THIS toolchain's libhiprtc (the directory the library resolved, or the one it was built against) in a process that holds
 // no other ROCm, runs the one compilation the request file describes and writes the code object, the lowered kernel names
 // and the log to the result file.  It never touches a GPU: hiprtc compiles for the --offload-arch it is given.
 //   exit code 0: a result file was written (its status says whether the compilation succeeded); 2: bad arguments / files.
@@ -19,7 +19,6 @@ int main(int argc, char **argv)
     ptrtc::Result r;
     ptrtc::Rtc rtc;
     std::vector<std::string> candidates;
-    if (const char *forced = getenv("PATHTRACE_HIP_RTC_LIB")) candidates.push_back(forced);
     // the directory the library resolved when it started this process (pt_spec.cpp rocm_lib_dir), then the one this helper was
     // built against, then the usual place; by soname last (the environment pt_spec.cpp gives this process has LD_LIBRARY_PATH =
     // that directory, so hiprtc's own dlopen of libamd_comgr finds the same toolchain's)

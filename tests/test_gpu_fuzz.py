@@ -90,9 +90,9 @@ def test_large_instance_counts(oracle):
     o, oc = osc.render_stream(oracle.make_config(24, 18, 2, light_samples=2), seed=3, threads=2)
     for env in (None, "1", "walk"):   # fast sweep over the tree program / general sweep / per-lane walk
         if env == "1":
-            os.environ["PATHTRACE_HIP_NO_FASTDIV"] = env
+            os.environ["PATHTRACE_HIP_TRAVERSAL"] = "general"
         elif env == "walk":
-            os.environ["PATHTRACE_HIP_FORCE_WALK"] = "1"
+            os.environ["PATHTRACE_HIP_TRAVERSAL"] = "walk"
         try:
             big = pt.Scene(text=json.dumps(js), width=24, height=18)
             rb = pt.Renderer(big, seed=3, light_samples=2)
@@ -100,8 +100,7 @@ def test_large_instance_counts(oracle):
             gc = rb.counters()
             rb.close()
         finally:
-            os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
-            os.environ.pop("PATHTRACE_HIP_FORCE_WALK", None)
+            os.environ.pop("PATHTRACE_HIP_TRAVERSAL", None)
         assert ((bits(g) == bits(o)) | (g == o)).all(), env
         assert all(gc[a] == oc[b] for a, b in CTR.items()), env
 

@@ -28,7 +28,7 @@ def test_contexts_on_one_gpu_reassemble_the_single_context_image(scene, n_ctx, m
     single.close()
     for rr in (False, True):
         if rr:
-            monkeypatch.setenv("PATHTRACE_HIP_ROUND_ROBIN", "1")
+            monkeypatch.setenv("PATHTRACE_HIP_MULTI", "roundrobin")
         m = pt.MultiRenderer(sc, [0] * n_ctx, seed=2, block=64)
         owners = m.tile_owners()
         assert len(owners) == -(-w // 64) * -(-h // 64) and set(owners) == set(range(n_ctx))
@@ -53,7 +53,7 @@ def test_contexts_on_one_gpu_reassemble_the_single_context_image(scene, n_ctx, m
         m.render_async(0, 1)
         assert m.counters()["camera_samples"] == w * h
         m.close()
-        monkeypatch.delenv("PATHTRACE_HIP_ROUND_ROBIN", raising=False)
+        monkeypatch.delenv("PATHTRACE_HIP_MULTI", raising=False)
 
 
 def test_rccl_reduce_with_one_device(monkeypatch):
@@ -63,7 +63,7 @@ def test_rccl_reduce_with_one_device(monkeypatch):
     single = pt.Renderer(sc)
     ref = single.render(spp)
     single.close()
-    monkeypatch.setenv("PATHTRACE_HIP_MULTI_RCCL", "1")
+    monkeypatch.setenv("PATHTRACE_HIP_MULTI", "rccl")
     m = pt.MultiRenderer(sc, [0])
     m.render_async(0, spp)
     assert np.array_equal(bits(m.framebuffer()), bits(ref))

@@ -103,11 +103,11 @@ def test_bit_exact_config_variants(oracle, scene, kw):
 def test_hits_without_a_shadow_record_change_nothing(oracle, scene, monkeypatch):
     # k_shade stages a hit's light samples in LDS and writes no shadow record when none of them can contribute (every
     # coefficient +-0 or NaN: surfaces facing away from the light, hits on the light); their shadow rays are counted, not
-    # traced.  With PATHTRACE_HIP_NO_STAGE=1 every hit gets its record: same bits, same counters, both equal to the oracle.
+    # traced.  With PATHTRACE_HIP_SHADE=nostage every hit gets its record: same bits, same counters, both equal to the oracle.
     w, h, spp = 128, 72, 8
     ref, oc = oracle.Scene.from_json(scene_path(scene)).render_stream(oracle_cfg(oracle, w, h, spp), seed=9)
     staged, c0 = gpu_render(scene, w, h, spp, seed=9)
-    monkeypatch.setenv("PATHTRACE_HIP_NO_STAGE", "1")
+    monkeypatch.setenv("PATHTRACE_HIP_SHADE", "nostage")
     plain, c1 = gpu_render(scene, w, h, spp, seed=9)
     traced = ("rays_traced", "shadow_rays_traced")
     assert np.array_equal(bits(staged), bits(plain)) and {k: v for k, v in c0.items() if k not in traced} == {k: v for k, v in c1.items() if k not in traced}
@@ -123,10 +123,9 @@ def test_chunk_sort_by_shading_class_changes_nothing(scene, monkeypatch):
     # k_shade's counting sort of a chunk by shading class is on by default only for textured scenes and scenes of more
     # than two lights; forced on and off, the image and the counters are the same (per-path arithmetic is lane-free)
     w, h, spp = 128, 72, 8
-    monkeypatch.setenv("PATHTRACE_HIP_SORT", "1")
+    monkeypatch.setenv("PATHTRACE_HIP_SHADE", "sort")
     a, ca = gpu_render(scene, w, h, spp, seed=4)
-    monkeypatch.delenv("PATHTRACE_HIP_SORT")
-    monkeypatch.setenv("PATHTRACE_HIP_NO_SORT", "1")
+    monkeypatch.setenv("PATHTRACE_HIP_SHADE", "nosort")
     b, cb = gpu_render(scene, w, h, spp, seed=4)
     assert np.array_equal(bits(a), bits(b)) and ca == cb
 
@@ -173,7 +172,7 @@ def test_multi_rect_batches_at_the_allocation_edge(max_paths, monkeypatch):
     # as the whole frame in one batch with the default segments.
     scene, w, h, spp = "cornell_box", 128, 64, 5
     whole, c0 = gpu_render(scene, w, h, spp)
-    monkeypatch.setenv("PATHTRACE_HIP_SEG", "256")
+    monkeypatch.setenv("PATHTRACE_HIP_PLAN", "seg=256")
     sc = pt.Scene(scene_path(scene), w, h)
     r = pt.Renderer(sc, max_paths_in_flight=max_paths)
     tiles = pt.spiral_tiles(w, h, 64, 64)

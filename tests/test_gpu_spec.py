@@ -14,12 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(params=["extend", "extend+connect"])
 def spec_sync(monkeypatch, request):
-    # the module serves k_extend, k_connect and k_trace; PATHTRACE_HIP_SPEC_CONNECT=0 leaves shadow rays on the generic k_connect
-    monkeypatch.setenv("PATHTRACE_HIP_SPEC", "sync")
-    if request.param == "extend+connect":
-        monkeypatch.delenv("PATHTRACE_HIP_SPEC_CONNECT", raising=False)
-    else:
-        monkeypatch.setenv("PATHTRACE_HIP_SPEC_CONNECT", "0")
+    # the module serves k_extend, k_connect and k_trace; PATHTRACE_HIP_SPEC=sync,extend-only leaves shadow rays on the generic k_connect
+    monkeypatch.setenv("PATHTRACE_HIP_SPEC", "sync" if request.param == "extend+connect" else "sync,extend-only")
 
 
 @pytest.mark.parametrize("scene", ALL_SCENES)

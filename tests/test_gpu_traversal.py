@@ -203,8 +203,8 @@ def tame_rays(rng, sc, n_random=40000):
 @pytest.mark.parametrize("scene", ALL_SCENES)
 def test_fast_sweep_matches_oracle_and_general_sweep(oracle, scene, monkeypatch):
     """Every ray here takes world_hit_fast on the device (all lanes tame).  It must equal the oracle's World::hit bit
-    for bit, and so must the general sweep on the same rays (PATHTRACE_HIP_NO_FASTDIV=1 switches the fast one off) and the
-    per-lane walk that large scenes use (PATHTRACE_HIP_FORCE_WALK=1 selects it for these small ones)."""
+    for bit, and so must the general sweep on the same rays (PATHTRACE_HIP_TRAVERSAL=general switches the fast one off) and the
+    per-lane walk that large scenes use (PATHTRACE_HIP_TRAVERSAL=walk selects it for these small ones)."""
     rng = np.random.default_rng(21)
     sc = pt.Scene(scene_path(scene), 64, 64)
     o, d = tame_rays(rng, sc)
@@ -214,12 +214,11 @@ def test_fast_sweep_matches_oracle_and_general_sweep(oracle, scene, monkeypatch)
     hit, ot, inst = osc.world_hit_stream(o, d, k0, k1, vd)
     results = []
     for env in (None, "1", "walk"):   # fast sweep (flat or tree program) / general sweep / per-lane walk
-        monkeypatch.delenv("PATHTRACE_HIP_NO_FASTDIV", raising=False)
-        monkeypatch.delenv("PATHTRACE_HIP_FORCE_WALK", raising=False)
+        monkeypatch.delenv("PATHTRACE_HIP_TRAVERSAL", raising=False)
         if env == "1":
-            monkeypatch.setenv("PATHTRACE_HIP_NO_FASTDIV", env)
+            monkeypatch.setenv("PATHTRACE_HIP_TRAVERSAL", "general")
         elif env == "walk":
-            monkeypatch.setenv("PATHTRACE_HIP_FORCE_WALK", "1")
+            monkeypatch.setenv("PATHTRACE_HIP_TRAVERSAL", "walk")
         r = pt.Renderer(sc, max_paths_in_flight=4096)
         t, ids = r.trace_rays(o, d, k0, k1, vd)
         ginst = np.where(ids >= 0, ids >> 3, -1)
@@ -239,8 +238,7 @@ def test_fast_sweep_matches_oracle_and_general_sweep(oracle, scene, monkeypatch)
                 assert (same_t(tn[:, k], ot2) | (h2 == 0)).all(), (env, nr, k)
         results.append((env, 1, t.copy(), ids.copy()))
         r.close()
-    monkeypatch.delenv("PATHTRACE_HIP_NO_FASTDIV", raising=False)
-    monkeypatch.delenv("PATHTRACE_HIP_FORCE_WALK", raising=False)
+    monkeypatch.delenv("PATHTRACE_HIP_TRAVERSAL", raising=False)
     # fast == general == walk including the face of the hit (ids, not only instances)
     by = {(e, nr): (t_, i_) for e, nr, t_, i_ in results}
     for nr in (1, 2, 4):

@@ -234,3 +234,17 @@ def test_random_scenes_flatten_like_the_oracle(oracle):
             dm = d.materials[i]
             assert (dm.type, dm.texture) == (m.type, m.texture) and tuple(np.float32(x) for x in dm.color) == tuple(m.color), seed
         assert d.background_texture == P.background_texture and np.array_equal(bits(sc.camera()[:21]), bits(osc.camera(40, 30)[:21]))
+
+
+def test_the_library_reads_exactly_the_documented_environment_variables():
+    """at most twelve PATHTRACE_HIP_* variables, every one listed in the table of include/pathtrace_hip.h."""
+    import glob
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "pathtrace_amd", "csrc", "*", "*")):
+        if f.endswith((".cpp", ".hip", ".h")):
+            read |= set(re.findall(r'(?:getenv|get|env_token)\("(PATHTRACE_HIP_[A-Z_]+)"', open(f).read()))
+    header = open(os.path.join(ROOT, "include", "pathtrace_hip.h")).read()
+    table = header[header.index("environment variables the library reads"):header.index("Everything else that used to be a run-time knob")]
+    documented = set(re.findall(r"^ \*   (PATHTRACE_HIP_[A-Z_]+)", table, re.M))
+    assert read == documented, read ^ documented
+    assert len(read) <= 12

@@ -16,7 +16,7 @@ for i in $(seq 1 "$REPS"); do
       if [ "$v" != "main" ]; then export PATHTRACE_HIP_LIB=$R/pathtrace_amd/lib/libpathtrace_hip_$v.so; fi
       if [ -n "$envs" ]; then IFS=',' read -ra kv <<< "$envs"; for e in "${kv[@]}"; do export "$e"; done; fi
       SC=""; if [ -n "$AB_SCENE" ]; then SC="--scene $R/scenes/$AB_SCENE"; fi   # AB_SCENE=cornell_box_with_volume.json: another scene
-      timeout -k 10 300 python3 "$R/bench.py" $SC --steps "$STEPS" --warmup 2 --no-cpu-baseline --no-configs --no-scaling-proxy > "$OUT/${TAG}_${label}_$i.json" 2> "$OUT/${TAG}_${label}_$i.err"
+      timeout -k 10 300 python3 "$R/bench.py" $SC --steps "$STEPS" --warmup 2 --no-cpu-baseline --no-configs --no-scaling-proxy --no-plugin-path > "$OUT/${TAG}_${label}_$i.json" 2> "$OUT/${TAG}_${label}_$i.err"
     ) || { echo "run $label $i failed"; tail -3 "$OUT/${TAG}_${label}_$i.err"; exit 1; }
     python3 - "$OUT/${TAG}_${label}_$i.json" "$label" "$i" <<'PY'
 import json, sys

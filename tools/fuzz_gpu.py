@@ -4,7 +4,7 @@
     python tools/fuzz_gpu.py [first_seed] [n_seeds] > gpurun_out/fuzz.json
 
 For every seed: a generated scene (tests/scene_gen.py; varying instance counts so that both the flat program and the tree
-program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_NO_FASTDIV=1 on every 5th seed; light_samples
+program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_TRAVERSAL=general on every 5th seed; light_samples
 4, 1, 2, 7, 3 by seed so that k_shade's staged and unstaged instantiations both run; the chunk sort forced on for every 3rd
 seed and the staging forced off for every 7th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
 bits and all nine path counters must agree.  With PATHTRACE_HIP_SPEC=sync in the environment every scene is rendered by its own
@@ -38,15 +38,15 @@ def main():
         js = random_scene(seed) if n_inst is None else random_scene(seed, n_inst=n_inst, volume=(seed % 4 != 0))
         general = seed % 5 == 0
         if general:
-            os.environ["PATHTRACE_HIP_NO_FASTDIV"] = "1"
+            os.environ["PATHTRACE_HIP_TRAVERSAL"] = "general"
         else:
-            os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
+            os.environ.pop("PATHTRACE_HIP_TRAVERSAL", None)
         ls = [4, 1, 2, 7, 3][seed % 5 if not general else (seed // 5) % 5]
-        for k, on in (("PATHTRACE_HIP_SORT", seed % 3 == 0), ("PATHTRACE_HIP_NO_STAGE", seed % 7 == 0)):
-            if on:
-                os.environ[k] = "1"
-            else:
-                os.environ.pop(k, None)
+        shade = [tok for tok, on in (("sort", seed % 3 == 0), ("nostage", seed % 7 == 0)) if on]
+        if shade:
+            os.environ["PATHTRACE_HIP_SHADE"] = ",".join(shade)
+        else:
+            os.environ.pop("PATHTRACE_HIP_SHADE", None)
         try:
             sc = pt.Scene(text=json.dumps(js), width=96, height=64)
             r = pt.Renderer(sc, seed=seed, light_samples=ls)

@@ -10,12 +10,11 @@ R=$(pwd); OUT=$R/gpurun_out; mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for scene in cornell_box three_orbs textured_room light_test; do
-  for sort in NO_SORT SORT; do
+  for sort in nosort sort; do
     d=$OUT/${TAG}_n2_${scene}_${sort}
     rm -rf "$d"
     export PATHTRACE_HIP_LANES=1 PT_BENCH_MAX_PATHS=66355200
-    unset PATHTRACE_HIP_SORT PATHTRACE_HIP_NO_SORT
-    export PATHTRACE_HIP_${sort}=1
+    export PATHTRACE_HIP_SHADE=${sort}
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --output-format csv -d "$d" -- \
       python3 "$R/bench.py" --scene "$R/scenes/$scene.json" --steps 4 --warmup 1 --no-cpu-baseline --no-configs --no-scaling-proxy --no-plugin-path > "$d.log" 2>&1 || { echo "$scene $sort failed"; tail -3 "$d.log"; exit 1; }
     python3 "$R/tools/pmc_summary.py" "$d.json" "$d" > /dev/null

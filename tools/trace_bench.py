@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of World::hit through pt_trace_rays (k_trace): N interior rays of a scene, fast sweep then general
-sweep (PATHTRACE_HIP_NO_FASTDIV=1), for rays_per_origin 1 and 2.  Run under `rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU
+sweep (PATHTRACE_HIP_TRAVERSAL=general), for rays_per_origin 1 and 2.  Run under `rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU
 SQ_INSTS_SALU` and read the k_trace dispatches in order with tools/trace_bench.py --summarize <dir>: instructions per
 wave = per ray (one origin per lane)."""
 import csv
@@ -43,9 +43,9 @@ def main():
     d2 = rng.normal(0, 1, (n, 2, 3)).astype(np.float32)
     for env in (None, "1"):
         if env:
-            os.environ["PATHTRACE_HIP_NO_FASTDIV"] = env
+            os.environ["PATHTRACE_HIP_TRAVERSAL"] = "general"
         else:
-            os.environ.pop("PATHTRACE_HIP_NO_FASTDIV", None)
+            os.environ.pop("PATHTRACE_HIP_TRAVERSAL", None)
         r = pt.Renderer(sc, max_paths_in_flight=4096)
         t1, i1 = r.trace_rays(o, d1)
         t2, i2 = r.trace_rays(o, d2)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the traversal choices on generated scenes of many instances (tests/scene_gen.py): the per-lane walk
-(default above 48 instances), the fast sweep over the tree program (PATHTRACE_HIP_NO_WALK=1) and the general sweep
-(PATHTRACE_HIP_NO_FASTDIV=1).  Prints Mrays/s per scene size and checks that the three images are identical."""
+(default above 48 instances), the fast sweep over the tree program (PATHTRACE_HIP_TRAVERSAL=sweep) and the general sweep
+(PATHTRACE_HIP_TRAVERSAL=general).  Prints Mrays/s per scene size and checks that the three images are identical."""
 import json
 import os
 import sys
@@ -22,9 +22,8 @@ for n_inst in (30, 60, 120, 200, 300):
     sc = pt.Scene(text=json.dumps(js), width=1024, height=768)
     imgs = {}
     row = {}
-    for name, env in (("walk", {"PATHTRACE_HIP_FORCE_WALK": "1"}), ("fast_sweep", {"PATHTRACE_HIP_NO_WALK": "1"}), ("general_sweep", {"PATHTRACE_HIP_NO_FASTDIV": "1"})):
-        for k in ("PATHTRACE_HIP_FORCE_WALK", "PATHTRACE_HIP_NO_WALK", "PATHTRACE_HIP_NO_FASTDIV"):
-            os.environ.pop(k, None)
+    for name, env in (("walk", {"PATHTRACE_HIP_TRAVERSAL": "walk"}), ("fast_sweep", {"PATHTRACE_HIP_TRAVERSAL": "sweep"}), ("general_sweep", {"PATHTRACE_HIP_TRAVERSAL": "general"})):
+        os.environ.pop("PATHTRACE_HIP_TRAVERSAL", None)
         os.environ.update(env)
         r = pt.Renderer(sc, seed=1, max_paths_in_flight=1024 * 768 * 8)
         r.render_async(0, 8); r.wait(); r.clear()
