@@ -846,7 +846,7 @@ static int stream_alloc(pt_ctx *c, T **p, size_t n)
 // The wavefront streams of every lane for `want` path slots per batch.  Called by pt_create (an explicit
 // max_paths_in_flight), by pt_reserve and by the first render call of an auto-sized context -- and again when a later call's
 // plan wants more slots than the context owns: every lane goes idle, the old streams are freed, the new ones allocated.
-static int size_streams(pt_ctx *c, int64_t want)
+static int size_streams_once(pt_ctx *c, int64_t want)
 {
     want = std::max<int64_t>(want, 64);
     // a path slot travels as an int32 whose bit 31 is the `pending` flag (k_shade / k_connect), segment counts and pixel
@@ -894,6 +894,33 @@ static int size_streams(pt_ctx *c, int64_t want)
     c->plan.path_slots = c->P;
     c->plan.stream_bytes = (int64_t)(P * slot_bytes(c) * (size_t)c->n_lanes_alloc);
     return 0;
+}
+
+static void drop_streams(pt_ctx *c)
+{
+    for (void *p : c->stream_allocs) (void)hipFree(p);
+    c->stream_allocs.clear();
+    for (int l = 0; l < PT_MAX_LANES; l++) {   // no stale plane pointers: a lane without streams has none
+        DStreams &st = c->lanes[l].st;
+        for (int i = 0; i < 2; i++) st.q[i] = DQueue{};
+        st.sq = DShadowQueue{};
+        st.hit = nullptr; st.radiance = nullptr; st.pending = nullptr;
+    }
+    c->P = 0; c->P_phys = 0; c->n_seg_max = 0;
+    c->plan.path_slots = 0; c->plan.stream_bytes = 0;
+}
+// An allocation that fails half-way leaves nothing behind; an auto-sized context then tries again with half the slots (another
+// process may hold memory hipMemGetInfo did not show as taken yet), an explicit size fails loudly.
+static int size_streams(pt_ctx *c, int64_t want)
+{
+    for (;;) {
+        if (size_streams_once(c, want) == 0) return 0;
+        const std::string why = g_err;
+        (void)hipGetLastError();
+        drop_streams(c);
+        if (!c->auto_size || want <= ((int64_t)1 << 20)) { g_err = why; return -1; }
+        want /= 2;
+    }
 }
 
 // Path slots the plan wants for calls of `pixels` x `samples` on an auto-sized context: pixels x its samples per batch, within

@@ -99,11 +99,6 @@ namespace ptd {
 #ifndef PT_VOL_LAZY_DRAW
 #define PT_VOL_LAZY_DRAW 1   // ... and the free-flight draw only in waves where some ray crosses the medium (0: every wave draws, the A/B)
 #endif
-#ifndef PT_BOX3
-#define PT_BOX3 0            // EXPERIMENT, not exact (DESIGN.md 4.2 "one fold per box axis"): per box axis only the face a convex box can be hit on
-                             // first (the near plane when its t >= t_min, else the far one) is folded.  1: no guard at all -- the upper bound
-                             // of what the idea can buy; the excluded face can win where rounding rejects the entry face near an edge
-#endif
 #ifndef PT_FAST_RB
 #define PT_FAST_RB 1         // scenes of rects and boxes: the fast sweep with box faces in the global fold (world_hit_fast_rb); 0: world_hit_fast
 #endif
@@ -1247,17 +1242,8 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
                         if (rot) chk = __builtin_fmaf(0.0f, rc, chk);                                                    \
                         fdiv_q2_nofix(n0, n1, Bl[r].DPL, rc, t0, t1);                                                    \
                     }                                                                                                    \
-                    if (PT_BOX3 && !IEEE_) {                                                                             \
-                        const bool n0near = t0 < t1;   /* equal quotients: the later side (F0 + 1) is the one the reference keeps */ \
-                        const float tn = n0near ? t0 : t1, tf = n0near ? t1 : t0;                                        \
-                        const bool use_near = !(tn < T_MIN);                                                             \
-                        const float ts = use_near ? tn : tf;                                                             \
-                        const int ids = (use_near == n0near) ? op_id_base + (F0) : op_id_base + (F0) + 1;                \
-                        face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, ts, OX, OZ, Bl[r], skip[r], ids, cur_t[r], cur_id[r], chk); \
-                    } else {                                                                                             \
                     face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t0, OX, OZ, Bl[r], skip[r], op_id_base + (F0), cur_t[r], cur_id[r], chk);     \
                     face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t1, OX, OZ, Bl[r], skip[r], op_id_base + (F0) + 1, cur_t[r], cur_id[r], chk); \
-                    }                                                                                                    \
                 }                                                                                                        \
             }
 #define BOX_LEAF(IEEE_)                                                                                                  \

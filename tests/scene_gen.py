@@ -1,11 +1,13 @@
 """Seeded random scenes in the reference's scene-JSON schema (scene_parser.h:104-595), for parity sweeps beyond the
 hand-authored scenes: arbitrary rotations and (non-uniform) scales, rect / box / sphere primitives in all alignments, refs
 and direct instances, several lights (rect and sphere), metal / dielectric, an optional constant_medium with a box
-boundary, optional checker / perlin textures on surfaces, emitter and background.  Test infrastructure only."""
+boundary, optional checker / perlin textures on surfaces, emitter and background; `nested=True` adds a medium whose
+boundary is a medium (box or sphere innermost; the default leaves the seeds the fixtures were made with as they are).
+Test infrastructure only."""
 import numpy as np
 
 
-def random_scene(seed: int, n_inst=None, volume=None, textures=None):
+def random_scene(seed: int, n_inst=None, volume=None, textures=None, nested=False):
     rng = np.random.default_rng(seed)
     u = lambda a, b: float(np.float32(rng.uniform(a, b)))
     col = lambda lo=0.05, hi=0.95: [u(lo, hi), u(lo, hi), u(lo, hi)]
@@ -55,6 +57,13 @@ def random_scene(seed: int, n_inst=None, volume=None, textures=None):
         prims.append({"id": "vbox", "type": "box", "size": [u(100, 400), u(100, 400), u(100, 400)]})
         prims.append({"id": "fog", "type": "volume", "primitive": "vbox", "density": u(0.0005, 0.02), "color": col(0.3, 1.0)})
 
+    if nested:   # appended after everything the default draws: earlier seeds keep their scenes
+        inner = "nbox" if rng.integers(0, 2) else "nball"
+        prims.append({"id": "nbox", "type": "box", "size": [u(100, 300), u(100, 300), u(100, 300)]} if inner == "nbox"
+                     else {"id": "nball", "type": "sphere", "radius": u(60, 160), "material": {"id": surf[0]}})
+        prims.append({"id": "fog_in", "type": "volume", "primitive": inner, "density": u(0.005, 0.05), "color": col(0.3, 1.0)})
+        prims.append({"id": "fog_out", "type": "volume", "primitive": "fog_in", "density": u(0.003, 0.03), "color": col(0.3, 1.0)})
+
     def xf():
         t = {"translate": [u(0, 555), u(0, 555), u(0, 555)]}
         r = rng.integers(0, 4)
@@ -72,7 +81,7 @@ def random_scene(seed: int, n_inst=None, volume=None, textures=None):
     inst = []
     for i in range(n_inst):
         if rng.integers(0, 3) == 0:
-            e = {"type": "ref", "primitive": {"id": str(rng.choice([p["id"] for p in prims if p["type"] != "box" or p["id"] != "vbox"]))},
+            e = {"type": "ref", "primitive": {"id": str(rng.choice([p["id"] for p in prims if p["id"] not in ("vbox", "nbox", "nball", "fog_in")]))},
                  "transform": xf()}
         else:
             e = {"type": "direct", "primitive": prim(str(rng.choice(surf))), "transform": xf()}
@@ -82,6 +91,8 @@ def random_scene(seed: int, n_inst=None, volume=None, textures=None):
     for i in range(int(rng.integers(1, 4))):
         kind = "sphere" if rng.integers(0, 3) == 0 else "rect"
         inst.append({"type": "direct", "primitive": prim(str(rng.choice(lights)), kind), "transform": xf()})
+    if nested:
+        inst.append({"type": "ref", "primitive": {"id": "fog_out"}, "transform": xf()})
     order = rng.permutation(len(inst))
     inst = [inst[k] for k in order]
     world = {"color": col(0.0, 0.4)}

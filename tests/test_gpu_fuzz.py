@@ -51,8 +51,8 @@ def test_random_scenes_match_the_oracle(oracle):
     import json
     from scene_gen import random_scene
 
-    for seed in list(range(0, 24)) + [101, 202, 303, 404]:
-        js = random_scene(seed)
+    for seed in list(range(0, 24)) + [101, 202, 303, 404, 1001, 1002, 1003, 1004]:
+        js = random_scene(seed, nested=seed > 1000)   # the last four: with a medium whose boundary is a medium (general sweep)
         sc = pt.Scene(text=json.dumps(js), width=48, height=36)
         r = pt.Renderer(sc, seed=seed)
         g = r.render(3)
