@@ -6,7 +6,7 @@
 For every seed: a generated scene (tests/scene_gen.py; varying instance counts so that both the flat program and the tree
 program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_TRAVERSAL=general on every 5th seed; light_samples
 4, 1, 2, 7, 3 by seed so that k_shade's staged and unstaged instantiations both run; the chunk sort forced on for every 3rd
-seed and the staging forced off for every 7th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
+seed and the staging forced off for every 7th, a medium inside a medium on every 9th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
 bits and all nine path counters must agree.  With PATHTRACE_HIP_SPEC=sync in the environment every scene is rendered by its own
 build of the traversal kernels (counted as "per_scene_build")."""
 import json
@@ -35,7 +35,8 @@ def main():
     bad, rays, modes = [], 0, {"flat": 0, "tree": 0, "general": 0}
     for seed in range(first, first + n):
         n_inst = [None, 6, 12, 30, 60, 120][seed % 6]
-        js = random_scene(seed) if n_inst is None else random_scene(seed, n_inst=n_inst, volume=(seed % 4 != 0))
+        nested = seed % 9 == 0   # a medium whose boundary is a medium (round 5): the general sweep carries the whole scene
+        js = random_scene(seed, nested=nested) if n_inst is None else random_scene(seed, n_inst=n_inst, volume=(seed % 4 != 0), nested=nested)
         general = seed % 5 == 0
         if general:
             os.environ["PATHTRACE_HIP_TRAVERSAL"] = "general"
@@ -65,7 +66,9 @@ def main():
         ok = bool(same.all()) and all(gc[a] == oc[b] for a, b in CTR.items())
         rays += gc["rays"]
         modes["staged" if (ls <= 4 and seed % 7 != 0) else "unstaged"] = modes.get("staged" if (ls <= 4 and seed % 7 != 0) else "unstaged", 0) + 1
-        modes["general" if general else ("flat" if sc.desc.n_instances <= 24 else "tree")] += 1
+        modes["general" if (general or nested) else ("flat" if sc.desc.n_instances <= 24 else "tree")] += 1
+        if nested:
+            modes["nested_medium"] = modes.get("nested_medium", 0) + 1
         if not ok:
             bad.append({"seed": seed, "mismatched": int((~same).sum())})
         print(f"seed {seed} inst {sc.desc.n_instances} {'ok' if ok else 'MISMATCH'}", file=sys.stderr, flush=True)

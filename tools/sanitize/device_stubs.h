@@ -22,3 +22,13 @@ extern "C" int pt_multi_device_count(pt_multi *) { return 0; }
 extern "C" int pt_multi_get_device_counters(pt_multi *, int32_t, pt_counters *) { return -1; }
 extern "C" uint64_t pt_multi_exchange_bytes(pt_multi *) { return 0; }
 extern "C" int pt_spec_info(pt_ctx *, char *, size_t) { return -1; }
+// ABI v6 (the launch plan): referenced by the HipWavefront mirror in pt_host.cpp
+extern "C" int pt_reserve(pt_ctx *, int64_t, int32_t) { return -1; }
+extern "C" int pt_prime(pt_ctx *, int32_t, const int32_t *, int32_t) { return -1; }
+extern "C" int pt_get_plan(pt_ctx *, pt_plan *) { return -1; }
+extern "C" double pt_render_seconds(pt_ctx *) { return -1.0; }
+extern "C" int pt_wait_for(pt_ctx *, int32_t) { return -1; }
+extern "C" int pt_spec_wait(pt_ctx *) { return -1; }
+extern "C" int pt_multi_reserve(pt_multi *, int32_t, int32_t) { return -1; }
+extern "C" double pt_multi_render_seconds(pt_multi *) { return -1.0; }
+extern "C" int pt_multi_wait_for(pt_multi *, int32_t) { return -1; }
