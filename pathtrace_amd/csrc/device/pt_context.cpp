@@ -282,6 +282,27 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
         }
         default: return -1;
         }
+        // Wave-level leaf cull (pt_kernels.hip wave_skips_cullable): a box, or a medium on a box, carries the instance's world
+        // bounding box (instance::bbox, primitive.h:272-296) ENLARGED by a margin that dominates every rounding between the exact
+        // line and the hit points rect::hit computes (g[10..15]; bit 6 of slot): a wave none of whose rays touches it skips the
+        // leaf.  Only for coordinates within 2^12 and scales within 2^+-4, where the margin's argument holds.
+        if (op.kind == OP_LEAF_BOX || op.kind == OP_LEAF_VOLBOX) {
+            bool ok = true;
+            float ext = 0.0f;
+            for (int k = 0; k < 3; k++) {
+                ok = ok && std::isfinite(in.bbox[k]) && std::isfinite(in.bbox[k + 3]) && std::fabs(in.bbox[k]) <= 4096.0f && std::fabs(in.bbox[k + 3]) <= 4096.0f;
+                ext = std::max(ext, in.bbox[k + 3] - in.bbox[k]);
+            }
+            for (int r = 0; r < 3; r++) {   // column norms of the forward linear part: how far a local rounding error can travel in world space
+                const float c = std::fabs(in.fwd[r]) + std::fabs(in.fwd[4 + r]) + std::fabs(in.fwd[8 + r]);
+                ok = ok && c >= 0.0625f && c <= 16.0f;
+            }
+            if (ok) {
+                const float m = 0.25f + ext * 0.015625f;
+                for (int k = 0; k < 3; k++) { op.g[10 + k] = in.bbox[k] - m; op.g[13 + k] = in.bbox[k + 3] + m; }
+                op.slot |= 64;
+            }
+        }
         ops.push_back(op);
         return 0;
     }
@@ -511,6 +532,17 @@ static int spec_header_text(const pt_scene_desc *sc, std::string &out)
         int enters = 0;
         for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) enters += hp.ops[i].kind == OP_ENTER;
         snprintf(line, sizeof line, "#define PT_SPEC_FLAT %d\n", (enters == 1 && hp.ops[hp.n_general + 1].kind == OP_ENTER) ? 1 : 0);
+        out += line;
+    }
+    {   // leaves a whole wave may skip (bit 6 of DOp::slot): only worth a test when some leaf stays and some can go
+        int ncull = 0, nleaf = 0;
+        for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) {
+            const DOp &o = hp.ops[i];
+            if (o.kind < OP_LEAF_RECT_XY) continue;
+            nleaf++;
+            if ((o.slot & 64) && !(o.slot & 16)) ncull++;
+        }
+        snprintf(line, sizeof line, "#define PT_SPEC_NCULL %d\n", (ncull < nleaf) ? ncull : 0);
         out += line;
     }
     out += "static __device__ constexpr int kSpecW[PT_SPEC_N][32] = {\n";

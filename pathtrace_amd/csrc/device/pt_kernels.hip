@@ -93,6 +93,10 @@ namespace ptd {
 #ifndef PT_SYM_BOUNDS
 #define PT_SYM_BOUNDS 1      // per-scene build: faces centred on the local origin test |xh| - x1 instead of two differences (0: the A/B)
 #endif
+#ifndef PT_CULL_B0
+#define PT_CULL_B0 1           // per-scene build, k_extend of bounce 0: a wave of camera rays none of which can touch ANY box / medium leaf runs the program
+                               // without those leaves (wave_skips_cullable); 0: the A/B.  Measured for the other launches too and not used there (below)
+#endif
 #ifndef PT_VOL_SHARED
 #define PT_VOL_SHARED 1      // fast sweep, constant_medium on a box: both boundary queries from one evaluation of the six sides (0: box_hit_fast twice, the A/B)
 #endif
@@ -1137,7 +1141,9 @@ DEVI v3 vdivf_fast(v3 v, float d)
     return o;
 }
 template <bool B> struct BoolTag { static constexpr bool value = B; };
-template <int NR, bool GA>
+// NOCULL (per-scene build): the instantiation for waves none of whose rays can touch a cullable leaf (wave_skips_cullable): the same
+// straight-line program without those leaves.
+template <int NR, bool GA, bool NOCULL = false>
 DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                             const uint32_t (&vol_dim_base)[NR], float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -1175,6 +1181,7 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
         const int op_id_base = op_a * 8;
         const float pcf = __int_as_float(OPW(3));   // (float)pc, stored by the host (pt_context.cpp)
 #define OPF(i) __int_as_float(OPW(4 + (i)))
+        if (NOCULL && kind != OP_ENTER && (OPW(2) & 80) == 64) continue;   // (bit 6 without bit 4: a cullable leaf; this wave touches none of them)
         if (kind == OP_ENTER) {   // aabb::hit aabb.h:34-53, as in world_hit_fast
             const float dx0 = OPF(0) - A.x, dy0 = OPF(1) - A.y, dz0 = OPF(2) - A.z;
             const float dx1 = OPF(3) - A.x, dy1 = OPF(4) - A.y, dz1 = OPF(5) - A.z;
@@ -1495,8 +1502,60 @@ DEVI bool world_hit_walk(const DScene &S, bool lane_valid, v3 A, v3 B, uint32_t 
     return is_nanf(chk);
 }
 
+// Wave-level leaf cull (round 5, per-scene build of flat programs).  The node boxes of the Cornell scenes cull nothing per RAY (7.0 of 8
+// instances tested) and the flat program dropped them -- but the rays of one WAVE are coherent at bounce 0: 85 % of the
+// camera-ray waves and 63 % of the bounce-0 shadow sweeps of cornell_box 1080p touch neither block (software count over 40 rows).  For
+// every cullable leaf (a box, or a medium on a box: bit 6 of DOp::slot, enlarged world box in g[10..15]) the slab test of the enlarged box
+// on the exact reciprocals the sweep computes anyway; a wave in which NO ray touches ANY of them runs the instantiation without those
+// leaves -- two straight-line programs behind one scalar branch, not a branch per leaf (a per-leaf skip broke the sweep's one basic
+// block: k_connect +10 %, measured).  Used by k_extend's bounce-0 instantiation only (-4.5 % of k_extend): in k_connect the second
+// program costs the five-wave build 12 more spilled VGPRs (+23 %), and at four waves the cull only buys back what the fourth wave
+// loses (11.41 against 11.43 ms); at bounce 1 the waves are no longer coherent (profiles/experiments/r05_ab_runs.json, r05_cull*).  Conservative, so exact: a face the reference accepts has its computed hit point inside the
+// face's bounds; with coordinates within 2^12 and scales within 2^+-4 that point is within 2^-5 (world units) of the exact line at the
+// accepted t, the enlarged box is >= 0.25 further out, and the slab parameters' own error (2^-21 relative of |bound - origin| <= 2^13)
+// is 2^-8: the exact line is inside all three slabs at that t with room to spare, so "no ray touches" is never wrong.  The one hit
+// that needs no geometry -- t = 0 / 0 on a face whose plane holds the ray, accepted wherever the line runs -- needs a local
+// direction component that cancelled to exactly zero in a rotated leaf: such a ray counts as touching.
+#if defined(PT_SPEC_HEADER) && defined(PT_SPEC_NCULL)
+template <int NR>
+DEVI bool wave_skips_cullable(bool lane_valid, v3 A, const v3 (&B)[NR])
+{
+    if (PT_SPEC_NCULL == 0) return false;
+    bool touch = !(fmaxf(fmaxf(fabsf(A.x), fabsf(A.y)), fabsf(A.z)) <= 4096.0f);   // the margin's argument needs the origin within 2^12
+    v3 inv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {   // aabb.h:38, the sweep's own exact reciprocals (the compiler shares them with the sweep's)
+        const float rx = fdiv_rcp(B[r].x), ry = fdiv_rcp(B[r].y), rz = fdiv_rcp(B[r].z);
+        fdiv_q2_nofix_dd(1.0f, 1.0f, B[r].x, B[r].y, rx, ry, inv[r].x, inv[r].y);
+        inv[r].z = fdiv_q_nofix(1.0f, B[r].z, rz);
+    }
+#pragma unroll
+    for (int pc = 0; pc < PT_SPEC_N; ++pc) {
+        if (kSpecW[pc][0] < OP_LEAF_RECT_XY || (kSpecW[pc][2] & 80) != 64) continue;
+#define CF(i) __int_as_float(kSpecW[pc][4 + (i)])
+        const float lx = CF(22) - A.x, ly = CF(23) - A.y, lz = CF(24) - A.z, hx = CF(25) - A.x, hy = CF(26) - A.y, hz = CF(27) - A.z;
+        const int pat = kSpecW[pc][2] & 15;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const float ax = lx * inv[r].x, cx = hx * inv[r].x, ay = ly * inv[r].y, cy = hy * inv[r].y, az = lz * inv[r].z, cz = hz * inv[r].z;
+            const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fminf(az, cz)), 0.0f);
+            const float tf = fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fmaxf(az, cz));
+            touch = touch || !(tf < tn);
+            if (pat != 1) {   // a rotated leaf: an exactly zero local direction component (see above)
+                const float m[12] = {CF(0), CF(1), CF(2), CF(3), CF(4), CF(5), CF(6), CF(7), CF(8), CF(9), CF(10), CF(11)};
+                const v3 bl = (pat == 2) ? xf_axis_linear<0>(m, B[r]) : ((pat == 3) ? xf_axis_linear<1>(m, B[r]) : ((pat == 4) ? xf_axis_linear<2>(m, B[r]) : xf_linear(m, B[r])));
+                touch = touch || (fminf(fminf(fabsf(bl.x), fabsf(bl.y)), fabsf(bl.z)) == 0.0f);
+            }
+        }
+#undef CF
+    }
+    return !__any(touch && lane_valid);
+}
+#endif
+
 // World::hit for NR rays of one origin: picks the sweep for this wave (wave-uniform, one scalar branch).
-template <int NR, bool GA, bool WALK = false>
+// CULL: this instantiation may use the wave-level leaf cull (k_extend of bounce 0: camera rays)
+template <int NR, bool GA, bool WALK = false, bool CULL = false>
 DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                     const uint32_t (&vol_dim_base)[NR], Stk stk, float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -1519,7 +1578,15 @@ DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], u
         {
             // the round-4 form of the fast sweep (PT_FAST_RB=0: world_hit_fast, the A/B)
             bool redo;
-            if constexpr (PT_FAST_RB) redo = world_hit_fast_rb<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
+            if constexpr (PT_FAST_RB) {
+#if defined(PT_SPEC_HEADER) && defined(PT_SPEC_NCULL)
+                // (tame waves only: every direction component finite and non-zero, so the reciprocals of the test are finite)
+                if (CULL && PT_SPEC_NCULL > 0 && PT_SPEC_FLAT && wave_skips_cullable<NR>(lane_valid, A, B))
+                    redo = world_hit_fast_rb<NR, GA, true>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
+                else
+#endif
+                redo = world_hit_fast_rb<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
+            }
             else redo = world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
             general = __any(redo && lane_valid);
         }
@@ -2036,7 +2103,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_extend(DScene S, const DOp *__rest
         int id[1];
         const v3 Bd[1] = {V(r1.x, r1.y, r1.z)};
         const uint32_t vd[1] = {base_dim};
-        world_hit<1, GA, WALK>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
+        world_hit<1, GA, WALK, B0 && PT_CULL_B0 != 0>(S, valid, V(r0.x, r0.y, r0.z), Bd, k0, k1, vd, stk, t, id);
         if (valid) {
             // the hit stream carries the shading class of the face in bits 28-29 of the id (k_shade's sort key): one table
             // read here, at the end of a chunk, instead of a dependent one at the head of k_shade's
