@@ -2818,7 +2818,13 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
                 for (int k = 0; k < R; k++) { dn[k] = ld4<4>(&sq.d[(long long)(kg + R + k) * P + pos]); en[k] = ld2<4>(&sq.e[(long long)(kg + R + k) * P + pos]); }
             }
 #endif
+#ifdef PT_DBG_CONNECT_NOSWEEP   // timing only (wrong images; PATHTRACE_HIP_SPEC_FLAGS=-DPT_DBG_CONNECT_NOSWEEP): k_connect without its
+            // sweeps -- records, contribution, radiance -- measured 4.3 of 11.4 ms on cornell_box (profiles/experiments/r05_ab_runs.json r05_nosweep)
+#pragma unroll
+            for (int k = 0; k < R; k++) { t[k] = ldir[k].x + hp.x; id[k] = (t[k] == 12345.0f) ? 8 : -1; }
+#else
             world_hit<R, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
+#endif
             if (valid) {
 #pragma unroll
                 for (int k = 0; k < R; k++) connect_contribution<TEX>(S, hp, ldir[k], t[k], id[k], coef[k], pick_pdf, lc);   // k order = integrator.h:221
