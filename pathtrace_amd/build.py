@@ -76,7 +76,7 @@ def embed_sources(defs=()) -> None:
     # the -D flags of an A/B variant reach the per-scene hiprtc build too: the module and the library must be the same kernels
     # (a module built with the default flags beside a library built without the live-count bound faulted: one side never
     # wrote the words the other read).  The specialisation's own knobs are the module's business.
-    keep = [d for d in defs if d.startswith("-DPT_") and not d.startswith(("-DPT_SPEC_HEADER", "-DPT_CONNECT_WAVES", "-DPT_CONNECT_PREFETCH"))]
+    keep = [d for d in defs if d.startswith("-DPT_") and not d.startswith(("-DPT_SPEC_HEADER", "-DPT_CONNECT_WAVES", "-DPT_CONNECT_PREFETCH", "-DPT_CONNECT_NOHOIST"))]
     out = os.path.join(CSRC, "device", "pt_kernel_src_flags.inc")
     new = "".join('"%s",\n' % d.replace("\\", "\\\\").replace('"', '\\"') for d in keep) + "nullptr\n"
     if not os.path.exists(out) or open(out).read() != new:

@@ -103,6 +103,9 @@ namespace ptd {
 #ifndef PT_VOL_LAZY_DRAW
 #define PT_VOL_LAZY_DRAW 1   // ... and the free-flight draw only in waves where some ray crosses the medium (0: every wave draws, the A/B)
 #endif
+#ifndef PT_CONNECT_NOHOIST
+#define PT_CONNECT_NOHOIST 0   // k_connect: 1 = do not keep the per-leaf origin terms of a hit across its groups of rays (the A/B)
+#endif
 #ifndef PT_FAST_RB
 #define PT_FAST_RB 1         // scenes of rects and boxes: the fast sweep with box faces in the global fold (world_hit_fast_rb); 0: world_hit_fast
 #endif
@@ -2818,12 +2821,18 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
                 for (int k = 0; k < R; k++) { dn[k] = ld4<4>(&sq.d[(long long)(kg + R + k) * P + pos]); en[k] = ld2<4>(&sq.e[(long long)(kg + R + k) * P + pos]); }
             }
 #endif
+#if PT_CONNECT_NOHOIST   // the origin is re-read through an opaque move per group of rays: its per-leaf terms are formed again, not kept
+            v3 hq = hp;
+            asm volatile("" : "+v"(hq.x), "+v"(hq.y), "+v"(hq.z));
+#else
+            const v3 hq = hp;
+#endif
 #ifdef PT_DBG_CONNECT_NOSWEEP   // timing only (wrong images; PATHTRACE_HIP_SPEC_FLAGS=-DPT_DBG_CONNECT_NOSWEEP): k_connect without its
             // sweeps -- records, contribution, radiance -- measured 4.3 of 11.4 ms on cornell_box (profiles/experiments/r05_ab_runs.json r05_nosweep)
 #pragma unroll
             for (int k = 0; k < R; k++) { t[k] = ldir[k].x + hp.x; id[k] = (t[k] == 12345.0f) ? 8 : -1; }
 #else
-            world_hit<R, GA, WALK>(S, valid, hp, ldir, k0, k1, vd, stk, t, id);
+            world_hit<R, GA, WALK>(S, valid, hq, ldir, k0, k1, vd, stk, t, id);
 #endif
             if (valid) {
 #pragma unroll

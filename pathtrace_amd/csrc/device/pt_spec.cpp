@@ -225,8 +225,7 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     snprintf(e, sizeof e, "ptd::k_connect<%d, %s, %s, false>", connect_nr, tex, ga); q.exprs.push_back(e);
     for (int nr : {1, 2, 4}) { snprintf(e, sizeof e, "ptd::k_trace<%d, %s, false>", nr, ga); q.exprs.push_back(e); }
     // the product's flags (pathtrace_amd/build.py): no FMA contraction, IEEE division and square root; the specialised k_connect
-    // is compiled for 5 waves per SIMD (96 VGPRs: at 6 it spills 17) and without the early radiance request, which at this
-    // register budget is spilled the moment it arrives
+    // is compiled for AT LEAST 5 waves per SIMD (it reaches 6, see PT_CONNECT_NOHOIST below) and without the early radiance request
     const char *waves = "-DPT_CONNECT_WAVES=5";   // (4 and 6 measured in round 3: PATHTRACE_HIP_SPEC_FLAGS carries such options for an A/B)
     // -pragma-unroll-threshold: the sweep's op loop must unroll COMPLETELY for the table to fold into the code (kind, shapes and
     // constants are only compile-time values per unrolled iteration).  LLVM sizes the unrolled loop before it folds the per-kind
@@ -238,6 +237,12 @@ static std::shared_ptr<CodeObject> compile(const std::string &table, bool geom_a
     if (env.flags.find("pragma-unroll-threshold") == std::string::npos) { q.opts.push_back("-mllvm"); q.opts.push_back("-pragma-unroll-threshold=4000000"); }
     if (env.flags.find("PT_CONNECT_WAVES") == std::string::npos) q.opts.push_back(waves);
     if (env.flags.find("PT_CONNECT_PREFETCH") == std::string::npos) q.opts.push_back("-DPT_CONNECT_PREFETCH=0");
+    // Round 5: the origin's per-leaf terms (bound - origin for every face of the unrolled program: ~30 VGPRs) are NOT kept across a hit's
+    // groups of rays but formed again per group (+80 instructions per group): 96 VGPRs with 3 spilled -> 79 with none, six waves per
+    // SIMD instead of five, k_connect 11.5 -> 11.0 ms per 64 spp (+1.3 %); with sphere / medium leaves 128 VGPRs -> 96, five waves
+    // instead of four: with_volume +2.1 % (profiles/experiments/r05_ab_runs.json r05_nohoist*)
+    if (env.flags.find("PT_CONNECT_NOHOIST") == std::string::npos) q.opts.push_back("-DPT_CONNECT_NOHOIST=1");
+    if (env.flags.find("PT_CONNECT_WAVES_GA") == std::string::npos) q.opts.push_back("-DPT_CONNECT_WAVES_GA=5");
     for (const char *const *f = kBuildFlags; *f; f++) q.opts.push_back(*f);
     const std::string &extra = env.flags;   // measurement: more compiler options, space separated
     for (size_t i = 0; i < extra.size();) {

@@ -133,6 +133,25 @@ def test_the_table_folds_into_the_code(scene, tmp_path, monkeypatch):
     sc = pt.Scene(scene_path(scene), 64, 36)
     assert pt.spec_build_check(sc, 4) > 20000
     assert not _table_survives(out)
+    # ... and the register budget of the module's k_connect (round 5, pt_spec.cpp PT_CONNECT_NOHOIST): nothing spilled, six waves per
+    # SIMD (<= 80 VGPRs) for rects and boxes, five (<= 96) with sphere / medium leaves -- one more resident wave each than round 4
+    meta = _kernel_metadata(out, "k_connect")
+    assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0, meta
+    assert meta["vgpr_count"] <= (80 if scene == "cornell_box" else 96), meta
+
+
+def _kernel_metadata(code_object, name):
+    """The integer fields of one kernel's entry in the code object's metadata note (llvm-readelf --notes)."""
+    import os
+    import subprocess
+    from pathtrace_amd import build as ptb
+
+    llvm = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(ptb.HIPCC))), "lib", "llvm", "bin")
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(code_object)], capture_output=True, text=True).stdout
+    entries = notes.split("  - .agpr_count:")[1:]          # one entry per kernel, fields in alphabetical order
+    mine = [e for e in entries if re.search(r"\.name:\s+\S*" + name, e)]
+    assert len(mine) == 1, (name, len(entries))
+    return {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", mine[0], re.M)}
 
 
 def test_the_fold_check_trips_when_llvm_keeps_the_loop(tmp_path, monkeypatch):

@@ -11,7 +11,7 @@ for i in $(seq 1 "$REPS"); do
   for spec in "$@"; do
     v=${spec%%:*}; envs=""
     if [[ "$spec" == *:* ]]; then envs=${spec#*:}; fi
-    label=$(echo "$spec" | tr ':=,/' '____')
+    label=$(echo "$spec" | tr ':=,/ ' '_____')
     (
       if [ "$v" != "main" ]; then export PATHTRACE_HIP_LIB=$R/pathtrace_amd/lib/libpathtrace_hip_$v.so; fi
       if [ -n "$envs" ]; then IFS=',' read -ra kv <<< "$envs"; for e in "${kv[@]}"; do export "$e"; done; fi

@@ -37,7 +37,7 @@ def analyze(scene_file, light_samples=4, flags="", keep="", waves=5):
         f.write(f"template __global__ void ptd::k_extend<{ga}, false, false>({ARGS_EXT});\n")
         f.write(f"template __global__ void ptd::k_extend<{ga}, false, true>({ARGS_EXT});\n")
         f.write(f"template __global__ void ptd::k_connect<{nr}, false, {ga}, false>({ARGS_CON});\n")
-    fl = f"-DPT_CONNECT_WAVES={waves} -DPT_CONNECT_PREFETCH=0 -mllvm -pragma-unroll-threshold=4000000 -I{os.path.dirname(src)} " + flags   # pt_spec.cpp's options
+    fl = f"-DPT_CONNECT_WAVES={waves} -DPT_CONNECT_PREFETCH=0 -DPT_CONNECT_NOHOIST=1 -DPT_CONNECT_WAVES_GA=5 -mllvm -pragma-unroll-threshold=4000000 -I{os.path.dirname(src)} " + flags   # pt_spec.cpp's options
     return isa_stats.analyze(flags=fl, src=top, keep=keep)
 
 
