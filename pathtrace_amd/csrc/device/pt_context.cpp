@@ -213,6 +213,49 @@ static int volume_draws(const pt_scene_desc *sc, int pi)
     return n;
 }
 
+// Does the plane "local coordinate `axis` = k" of instance ii WALL THE SCENE IN (DOp::slot bit 5 for a rect, bits 8-13 for the six sides
+// of a box; pt_kernels.hip world_hit_fast_rb SHADOW)?  In the instance's own frame: every light's bounding box lies strictly on ONE
+// side of the plane -- at least 2^-10 of the farthest any point of the scene gets from it, so that "beyond the sample by 2^-12 of the
+// ray's length" holds for every origin -- and no corner of any other instance's bounding box, nor the primitive itself ([self_lo,
+// self_hi] along the axis), lies on the far side by more than rounding (2^-13 of the lights' distance).  A shadow ray, which joins a
+// point of some instance to a point of a light, then cannot cross the plane between t_min and the sample except by rounding at its
+// own ends, and that case the kernel tests per ray.  A performance choice only: the kernel's proof is per ray.
+static bool plane_walls_scene(const pt_scene_desc *sc, int ii, int axis, double k, double self_lo, double self_hi)
+{
+    const pt_instance &in = sc->instances[ii];
+    if (sc->n_lights < 1 || sc->n_nodes < 1) return false;
+    auto local = [&](const float *bbox, int c) {   // the corner's coordinate along the plane's axis, relative to the plane
+        const double x = bbox[(c & 1) ? 3 : 0], y = bbox[(c & 2) ? 4 : 1], z = bbox[(c & 4) ? 5 : 2];
+        return (double)in.inv[4 * axis] * x + (double)in.inv[4 * axis + 1] * y + (double)in.inv[4 * axis + 2] * z + (double)in.inv[4 * axis + 3] - k;
+    };
+    double side = 0.0, dmin = INFINITY, far = 0.0;
+    for (int l = 0; l < sc->n_lights; l++) {
+        const int li = sc->lights[l];
+        if (li < 0 || li >= sc->n_instances || li == ii) return false;
+        for (int c = 0; c < 8; c++) {
+            const double v = local(sc->instances[li].bbox, c);
+            if (!(std::fabs(v) > 0.0) || !std::isfinite(v)) return false;
+            if (side == 0.0) side = v > 0 ? 1.0 : -1.0;
+            if (v * side < 0.0) return false;
+            dmin = std::min(dmin, std::fabs(v));
+        }
+    }
+    for (int c = 0; c < 8; c++) far = std::max(far, std::fabs(local(sc->nodes[0].bbox, c)));
+    if (!(dmin >= far * 0x1p-10)) return false;
+    const double tol = dmin * 0x1p-13;
+    if (!((self_lo - k) * side >= -tol) || !((self_hi - k) * side >= -tol)) return false;
+    for (int j = 0; j < sc->n_instances; j++)
+        for (int c = 0; c < 8 && j != ii; c++) {   // (the instance's own box is padded by 0.001; its own extent was given exactly)
+            const double v = local(sc->instances[j].bbox, c);
+            if (!(v * side >= -tol)) return false;
+        }
+    return true;
+}
+static bool emits(const pt_scene_desc *sc, int material)
+{
+    return material < 0 || material >= sc->n_materials || sc->materials[material].type == PT_MAT_DIFFUSE_LIGHT;
+}
+
 // bvh_node tree -> sweep program (pt_device.h).  `pending_push` is the slot the NEXT emitted op must push into.
 static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<DOp> &ops, int &max_depth, int &pending_push)
 {
@@ -242,10 +285,17 @@ static int emit_ops(const pt_scene_desc *sc, int child, int depth, std::vector<D
         case PT_PRIM_RECT:
             op.kind = p.plane == PT_PLANE_XY ? OP_LEAF_RECT_XY : (p.plane == PT_PLANE_YZ ? OP_LEAF_RECT_YZ : OP_LEAF_RECT_XZ);
             memcpy(op.g, p.rect, 5 * sizeof(float));
+            if (!emits(sc, p.material) && plane_walls_scene(sc, ii, p.plane == PT_PLANE_XY ? 2 : (p.plane == PT_PLANE_YZ ? 0 : 1), p.rect[4], p.rect[4], p.rect[4]))
+                op.slot |= 32;
             break;
         case PT_PRIM_BOX:
             op.kind = OP_LEAF_BOX;
             memcpy(op.g, p.p0, 12); memcpy(op.g + 3, p.p1, 12);
+            // box::hit's sides in its order XY(p0.z) XY(p1.z) YZ(p0.x) YZ(p1.x) XZ(p0.y) XZ(p1.y) (primitive.h:229-242): bits 8-13
+            for (int f = 0; f < 6 && !emits(sc, p.material); f++) {
+                const int axis = f < 2 ? 2 : (f < 4 ? 0 : 1);
+                if (plane_walls_scene(sc, ii, axis, (f & 1) ? p.p1[axis] : p.p0[axis], p.p0[axis], p.p1[axis])) op.slot |= 256 << f;
+            }
             break;
         case PT_PRIM_SPHERE:
             op.kind = OP_LEAF_SPHERE;
@@ -543,6 +593,14 @@ static int spec_header_text(const pt_scene_desc *sc, std::string &out)
             if ((o.slot & 64) && !(o.slot & 16)) ncull++;
         }
         snprintf(line, sizeof line, "#define PT_SPEC_NCULL %d\n", (ncull < nleaf) ? ncull : 0);
+        out += line;
+        int nwall = 0;   // rects and box sides that wall the scene in (bits 5 / 8-13 of DOp::slot): k_connect proves them unreachable instead of testing them
+        for (int i = hp.n_general + 1; i < hp.n_general + 1 + hp.n_fast; i++) {
+            const DOp &o = hp.ops[i];
+            nwall += o.kind >= OP_LEAF_RECT_XY && o.kind <= OP_LEAF_RECT_YZ && (o.slot & 48) == 32;
+            if (o.kind == OP_LEAF_BOX && !(o.slot & 16)) nwall += __builtin_popcount((o.slot >> 8) & 63);
+        }
+        snprintf(line, sizeof line, "#define PT_SPEC_NWALL %d\n", nwall);
         out += line;
     }
     out += "static __device__ constexpr int kSpecW[PT_SPEC_N][32] = {\n";

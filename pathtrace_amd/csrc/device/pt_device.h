@@ -99,6 +99,9 @@ struct DOp {             // 128 bytes = two 64-byte halves, 128-byte aligned in 
     int32_t slot;        // COMBINE: short-stack slot;  LEAF: bits 0-3 shape of the inverse's linear part -- 0 general, 1 exactly
                          // the identity, 2 / 3 / 4 the x / y / z axis is mapped to itself (zero row and column off the
                          // diagonal); bit 4: the leaf's data are outside the precondition of the unscaled division
+                         // bit 5: a rect that walls the scene in (pt_context.cpp plane_walls_scene: shadow sweeps prove it unreachable),
+                         // bits 8-13: the same for the six sides of a box, in box::hit's order;
+                         // bit 6: a box / medium-on-a-box leaf with its enlarged world box in g[10..15] (wave-level cull)
     int32_t push_slot;   // >= 0: store the current partial result into this slot BEFORE executing the op
     float f[12];
     // second half: primitive parameters, needed only after the ray has been transformed

@@ -106,6 +106,9 @@ namespace ptd {
 #ifndef PT_CONNECT_NOHOIST
 #define PT_CONNECT_NOHOIST 0   // k_connect: 1 = do not keep the per-leaf origin terms of a hit across its groups of rays (the A/B)
 #endif
+#ifndef PT_SHADOW_WALLS
+#define PT_SHADOW_WALLS 1   // per-scene k_connect: the rects that wall the scene in are proven unreachable instead of tested (0: the A/B)
+#endif
 #ifndef PT_FAST_RB
 #define PT_FAST_RB 1         // scenes of rects and boxes: the fast sweep with box faces in the global fold (world_hit_fast_rb); 0: world_hit_fast
 #endif
@@ -1146,7 +1149,17 @@ DEVI v3 vdivf_fast(v3 v, float d)
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 // NOCULL (per-scene build): the instantiation for waves none of whose rays can touch a cullable leaf (wave_skips_cullable): the same
 // straight-line program without those leaves.
-template <int NR, bool GA, bool NOCULL = false>
+//
+// SHADOW (per-scene build, k_connect): the rays are shadow rays -- origin a hit point, direction = light sample - origin, so the
+// sample sits at t = 1 -- and all that is asked of the closest hit is whether it is an emitter (connect_contribution).  A rect that
+// WALLS THE SCENE IN (DOp::slot bit 5, set by the host: every instance on one side of its plane, the lights strictly inside, no
+// emitter itself) can only be crossed before t_min or beyond the sample, and its exact test is replaced by the proof that it is:
+// t~ = (plane - origin) * rcp(direction) outside [2^-11, 1 + 2^-12] (t~ is within 3 ulp of the quotient the reference forms, which is
+// then < t_min = 0.001 and rejected, primitive.h:193, or > 1 + 2^-13).  If afterwards the closest hit has t <= 1 + 2^-14 it is closer
+// than every such wall and stays the closest hit with them; no hit, or a non-emitter, stays "no contribution" whatever a wall behind
+// it would answer.  A ray that fails either test (t~ inside the interval or NaN: a grazing ray on the wall's own plane; a hit beyond
+// the sample) sends its wave to the general sweep like a NaN does.  cornell_box: five of seven rects, -20 % of the sweep.
+template <int NR, bool GA, bool NOCULL = false, bool SHADOW = false>
 DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                             const uint32_t (&vol_dim_base)[NR], float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -1154,6 +1167,13 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
     v3 inv[NR];
     float cur_t[NR], skipf[NR], chk = 0.0f;
     int cur_id[NR];
+    bool beyond = false;   // SHADOW: some wall's plane may be crossed inside (t_min, sample], or the closest hit lies beyond the sample
+    constexpr float kWallLo = 0x1p-11f, kWallHi = 1.0f + 0x1p-12f, kWallMid = 0.5f * (kWallLo + kWallHi), kWallHalf = 0.5f * (kWallHi - kWallLo);
+#if defined(PT_SPEC_HEADER) && defined(PT_SPEC_NWALL)
+    constexpr bool kBoxWalls = SHADOW && PT_SHADOW_WALLS != 0;
+#else
+    constexpr bool kBoxWalls = false;
+#endif
 #pragma unroll
     for (int r = 0; r < NR; r++) {
         {   // aabb.h:38: 1 / direction, exact; tame components are finite and non-zero: no fix-up, x and y as a packed pair
@@ -1244,16 +1264,23 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
 #define BOX_AXIS(IEEE_, PLANE, DPL, X0, Z0, X1, Z1, N0, N1, OX, OZ, F0)                                                    \
             {                                                                                                            \
                 const float n0 = (N0), n1 = (N1);                                                                        \
+                /* SHADOW: a side that walls the scene in (DOp::slot bits 8-13) is proven unreachable instead of tested, like a rect */ \
+                const bool wall0 = kBoxWalls && !(IEEE_) && ((OPW(2) >> (8 + (F0))) & 1), wall1 = kBoxWalls && !(IEEE_) && ((OPW(2) >> (9 + (F0))) & 1); \
                 _Pragma("unroll") for (int r = 0; r < NR; r++) {                                                         \
                     float t0, t1;                                                                                        \
+                    float rcw = 0.0f;                                                                                    \
                     if (IEEE_) { t0 = n0 / Bl[r].DPL; t1 = n1 / Bl[r].DPL; }                                             \
                     else {                                                                                               \
                         const float rc = fdiv_rcp(Bl[r].DPL);                                                            \
+                        rcw = rc;                                                                                        \
                         if (rot) chk = __builtin_fmaf(0.0f, rc, chk);                                                    \
-                        fdiv_q2_nofix(n0, n1, Bl[r].DPL, rc, t0, t1);                                                    \
+                        if (wall0 && wall1) { t0 = 0.0f; t1 = 0.0f; }                                                    \
+                        else fdiv_q2_nofix(n0, n1, Bl[r].DPL, rc, t0, t1);                                               \
                     }                                                                                                    \
-                    face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t0, OX, OZ, Bl[r], skip[r], op_id_base + (F0), cur_t[r], cur_id[r], chk);     \
-                    face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t1, OX, OZ, Bl[r], skip[r], op_id_base + (F0) + 1, cur_t[r], cur_id[r], chk); \
+                    if (wall0) beyond = beyond || !(fabsf(n0 * rcw - kWallMid) > kWallHalf);                              \
+                    else face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t0, OX, OZ, Bl[r], skip[r], op_id_base + (F0), cur_t[r], cur_id[r], chk);     \
+                    if (wall1) beyond = beyond || !(fabsf(n1 * rcw - kWallMid) > kWallHalf);                              \
+                    else face_fold_t<PLANE, IEEE_, !kFlat>(X0, Z0, X1, Z1, t1, OX, OZ, Bl[r], skip[r], op_id_base + (F0) + 1, cur_t[r], cur_id[r], chk); \
                 }                                                                                                        \
             }
 #define BOX_LEAF(IEEE_)                                                                                                  \
@@ -1262,6 +1289,26 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
             BOX_AXIS(IEEE_, 2, x, q0[1], q0[2], q1[1], q1[2], q0[0] - Al.x, q1[0] - Al.x, Al.y, Al.z, 2)                  \
             BOX_AXIS(IEEE_, 1, y, q0[0], q0[2], q1[0], q1[2], q0[1] - Al.y, q1[1] - Al.y, Al.x, Al.z, 4)                  \
         }
+#if defined(PT_SPEC_HEADER) && defined(PT_SPEC_NWALL)
+#define WALL_LEAF(PLANE, DPL)                                                                                            \
+        {                                                                                                                \
+            float ox, opl, oz;                                                                                           \
+            rect_axes<PLANE>(Al, ox, opl, oz);                                                                           \
+            const float num = q1[1] - opl;                                                                               \
+            _Pragma("unroll") for (int r = 0; r < NR; r++)                                                               \
+            {                                                                                                            \
+                const float tq = num * fdiv_rcp(Bl[r].DPL);                                                              \
+                beyond = beyond || !(fabsf(tq - kWallMid) > kWallHalf);                                                  \
+            }                                                                                                            \
+        }
+        if (SHADOW && PT_SHADOW_WALLS && (OPW(2) & 48) == 32 && kind >= OP_LEAF_RECT_XY && kind <= OP_LEAF_RECT_YZ) {
+            if (kind == OP_LEAF_RECT_XY) { asm volatile("; wall xy"); WALL_LEAF(0, z) }
+            else if (kind == OP_LEAF_RECT_YZ) { asm volatile("; wall yz"); WALL_LEAF(2, x) }
+            else { asm volatile("; wall xz"); WALL_LEAF(1, y) }
+            continue;
+        }
+#undef WALL_LEAF
+#endif
         if (kind == OP_LEAF_RECT_XY) { if (op_ieee) { asm volatile("; rect xy ieee"); RECT_LEAF(0, z, true) } else { asm volatile("; rect xy"); RECT_LEAF(0, z, false) } }
         else if (kind == OP_LEAF_RECT_YZ) { if (op_ieee) { asm volatile("; rect yz ieee"); RECT_LEAF(2, x, true) } else { asm volatile("; rect yz"); RECT_LEAF(2, x, false) } }
         else if (kind == OP_LEAF_RECT_XZ) { if (op_ieee) { asm volatile("; rect xz ieee"); RECT_LEAF(1, y, true) } else { asm volatile("; rect xz"); RECT_LEAF(1, y, false) } }
@@ -1399,9 +1446,15 @@ DEVI bool world_hit_fast_rb(const DScene &S, bool lane_valid, v3 A, const v3 (&B
             chk = ((tmax <= tmin) && cur_id[r] >= 0) ? NAN : chk;
         }
     }
+#if defined(PT_SPEC_HEADER) && defined(PT_SPEC_NWALL)
+    if (SHADOW && PT_SHADOW_WALLS && PT_SPEC_NWALL > 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) beyond = beyond || (cur_id[r] >= 0 && !(cur_t[r] <= 1.0f + 0x1p-14f));
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < NR; r++) { out_t[r] = (cur_id[r] >= 0) ? cur_t[r] : 0.0f; out_id[r] = cur_id[r]; }
-    return is_nanf(chk);
+    return is_nanf(chk) || beyond;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1558,7 +1611,7 @@ DEVI bool wave_skips_cullable(bool lane_valid, v3 A, const v3 (&B)[NR])
 
 // World::hit for NR rays of one origin: picks the sweep for this wave (wave-uniform, one scalar branch).
 // CULL: this instantiation may use the wave-level leaf cull (k_extend of bounce 0: camera rays)
-template <int NR, bool GA, bool WALK = false, bool CULL = false>
+template <int NR, bool GA, bool WALK = false, bool CULL = false, bool SHADOW = false>
 DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], uint32_t k0, uint32_t k1,
                     const uint32_t (&vol_dim_base)[NR], Stk stk, float (&out_t)[NR], int (&out_id)[NR])
 {
@@ -1588,7 +1641,7 @@ DEVI void world_hit(const DScene &S, bool lane_valid, v3 A, const v3 (&B)[NR], u
                     redo = world_hit_fast_rb<NR, GA, true>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
                 else
 #endif
-                redo = world_hit_fast_rb<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
+                redo = world_hit_fast_rb<NR, GA, false, SHADOW>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
             }
             else redo = world_hit_fast<NR, GA>(S, lane_valid, A, B, k0, k1, vol_dim_base, out_t, out_id);
             general = __any(redo && lane_valid);
@@ -2832,7 +2885,7 @@ __global__ __launch_bounds__(PT_BLOCK, NR >= 4 ? 4 : (GA ? PT_CONNECT_WAVES_GA :
 #pragma unroll
             for (int k = 0; k < R; k++) { t[k] = ldir[k].x + hp.x; id[k] = (t[k] == 12345.0f) ? 8 : -1; }
 #else
-            world_hit<R, GA, WALK>(S, valid, hq, ldir, k0, k1, vd, stk, t, id);
+            world_hit<R, GA, WALK, false, true>(S, valid, hq, ldir, k0, k1, vd, stk, t, id);   // shadow rays: see world_hit_fast_rb SHADOW
 #endif
             if (valid) {
 #pragma unroll

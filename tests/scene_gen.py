@@ -101,3 +101,56 @@ def random_scene(seed: int, n_inst=None, volume=None, textures=None, nested=Fals
     cam = {"look_from": [u(-300, 850), u(50, 500), u(-900, -300)], "look_at": [u(150, 400), u(150, 400), u(150, 400)],
            "fov": u(25, 70), "aperture": float(rng.choice([0.0, 0.0, u(1, 20)])), "dist_to_focus": u(5, 800)}
     return {"camera": cam, "world": world, "assets": [], "textures": tex, "materials": mats, "primitives": prims, "instances": inst}
+
+
+def room_scene(seed: int):
+    """A closed room of rects (translated, and rotated by half and three-half turns like the reference's Cornell box builds its
+    ceiling and back wall) with one or two rect lights hung close under the ceiling, a block or two, sometimes a fog block and a
+    free-standing partition: the scenes whose walls the shadow sweep of the per-scene build proves unreachable instead of testing
+    (pt_context.cpp rect_walls_scene) -- with the lights at the distances where that choice flips.  Test infrastructure only."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(np.float32(rng.uniform(a, b)))
+    col = lambda lo=0.1, hi=0.9: [u(lo, hi), u(lo, hi), u(lo, hi)]
+    W, H, D = u(300, 900), u(250, 700), u(300, 900)
+    mats = [{"id": "white", "type": "lambertian", "data": {"color": col(0.6, 0.8)}},
+            {"id": "red", "type": "lambertian", "data": {"color": [u(0.5, 0.8), 0.05, 0.05]}},
+            {"id": "green", "type": "lambertian", "data": {"color": [0.1, u(0.4, 0.6), 0.1]}},
+            {"id": "metal", "type": "metal", "data": {"color": col(0.6, 1.0), "roughness": u(0, 1)}},
+            {"id": "light", "type": "diffuse_light", "data": {"color": col(0.5, 1.0), "power": u(5, 30),
+                                                              **({"two_sided": False} if rng.integers(0, 2) else {})}}]
+    prims = [{"id": "floor", "type": "rect", "material": {"id": "white"}, "size": [W, D]},
+             {"id": "back", "type": "rect", "material": {"id": "white"}, "size": [W, H]}]
+    inst = [{"type": "ref", "primitive": {"id": "floor"}, "transform": {"translate": [W / 2, 0.0, D / 2]}},
+            {"type": "ref", "primitive": {"id": "floor"}, "transform": {"rotate": [1.0, 0.0, 0.0], "translate": [W / 2, H, D / 2]}},
+            {"type": "ref", "primitive": {"id": "back"}, "transform": {"rotate": [1.5, 0.0, 0.0], "translate": [W / 2, H / 2, D]}},
+            {"type": "direct", "primitive": {"type": "rect", "material": {"id": "green"}, "size": [H, D], "align": "yz", "flip": True},
+             "transform": {"translate": [W, H / 2, D / 2]}},
+            {"type": "direct", "primitive": {"type": "rect", "material": {"id": "red"}, "size": [H, D], "align": "yz"},
+             "transform": {"translate": [0.0, H / 2, D / 2]}}]
+    if rng.integers(0, 2):   # a front wall too: the camera then sits inside
+        inst.append({"type": "direct", "primitive": {"type": "rect", "material": {"id": "white"}, "size": [W, H], "align": "xy"},
+                     "transform": {"translate": [W / 2, H / 2, 0.0]}})
+    for k in range(int(rng.integers(1, 3))):
+        # distance under the ceiling: from far inside the margin of rect_walls_scene (2^-10 of the room) to well outside it
+        gap = float(np.float32(rng.choice([0.05, 0.3, 0.6, 1.0, 3.0, 40.0])))
+        lw, ld = u(40, W / 3), u(40, D / 3)
+        inst.append({"type": "direct", "primitive": {"type": "rect", "material": {"id": "light"}, "size": [lw, ld]},
+                     "transform": {"translate": [u(lw, W - lw), H - gap, u(ld, D - ld)]}})
+    for k in range(int(rng.integers(1, 3))):
+        s = [u(40, W / 4), u(40, H / 2), u(40, D / 4)]
+        hd = 0.5 * float(np.hypot(s[0], s[2])) + 2.0   # the block turns about y inside the room, whatever the angle
+        inst.append({"type": "direct", "primitive": {"type": "box", "material": {"id": str(rng.choice(["white", "metal"]))}, "size": s},
+                     "transform": {"translate": [u(hd, W - hd), s[1] / 2, u(hd, D - hd)], "rotate": [0.0, u(-0.3, 0.3), 0.0]}})
+    if rng.integers(0, 3) == 0:
+        prims.append({"id": "vbox", "type": "box", "size": [u(60, W / 3), u(60, H / 2), u(60, D / 3)]})
+        prims.append({"id": "fog", "type": "volume", "primitive": "vbox", "density": u(0.002, 0.02), "color": col(0.5, 1.0)})
+        inst.append({"type": "ref", "primitive": {"id": "fog"}, "transform": {"translate": [u(W / 4, 3 * W / 4), H / 3, u(D / 4, 3 * D / 4)]}})
+    if rng.integers(0, 2):   # a partition inside the room: shadow rays do cross its plane, it must stay a tested leaf
+        inst.append({"type": "direct", "primitive": {"type": "rect", "material": {"id": "white"}, "size": [u(50, H / 2), u(50, D / 2)], "align": "yz"},
+                     "transform": {"translate": [u(W / 4, 3 * W / 4), H / 4, D / 2]}})
+    order = rng.permutation(len(inst))
+    inst = [inst[k] for k in order]
+    inside = bool(rng.integers(0, 2))
+    cam = {"look_from": [u(W / 4, 3 * W / 4), u(H / 4, 3 * H / 4), u(5, D / 4) if inside else -u(300, 900)],
+           "look_at": [u(W / 4, 3 * W / 4), u(H / 4, 3 * H / 4), D], "fov": u(30, 70), "aperture": 0.0, "dist_to_focus": 10.0}
+    return {"camera": cam, "world": {"color": [0.0, 0.0, 0.0]}, "assets": [], "textures": [], "materials": mats, "primitives": prims, "instances": inst}

@@ -112,3 +112,30 @@ def test_a_failed_build_falls_back_to_the_generic_kernels(monkeypatch):
     assert r.spec_status() == -1 and "fails on purpose" in pt.last_error()
     assert np.array_equal(bits(r.render(spp)), bits(ref))
     r.close()
+
+
+@pytest.mark.parametrize("light_samples", [4, 3])
+def test_walled_rooms_match_the_oracle_on_the_module(oracle, light_samples, monkeypatch):
+    # tests/scene_gen.py room_scene: closed rooms whose walls the module's k_connect proves unreachable for a shadow ray instead of
+    # testing them (world_hit_fast_rb SHADOW) -- with lights from 0.05 to 40 units under the ceiling (the marking flips between
+    # them), a partition that must stay a tested leaf, one-sided lights, fog, the camera inside or outside.  Bit for bit the
+    # oracle: framebuffer and counters; and the same through the generic kernels.
+    import json
+    from scene_gen import room_scene
+    from test_gpu_fuzz import CTR
+
+    for seed in range(10):
+        js = room_scene(seed)
+        sc = pt.Scene(text=json.dumps(js), width=56, height=40)
+        osc = oracle.Scene(oracle.sp.load_scene_params(js))
+        o, oc = osc.render_stream(oracle.make_config(56, 40, 3, light_samples=light_samples), seed=seed, threads=2)
+        for spec in ("sync", "off"):
+            monkeypatch.setenv("PATHTRACE_HIP_SPEC", spec)
+            r = pt.Renderer(sc, seed=seed, light_samples=light_samples)
+            assert r.spec_status() == (1 if spec == "sync" else -1), pt.last_error()
+            g = r.render(3)
+            gc = r.counters()
+            r.close()
+            assert ((bits(g) == bits(o)) | (g == o)).all(), (seed, spec)
+            for a, b in CTR.items():
+                assert gc[a] == oc[b], (seed, spec, a, gc[a], oc[b])

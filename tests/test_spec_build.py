@@ -163,3 +163,47 @@ def test_the_fold_check_trips_when_llvm_keeps_the_loop(tmp_path, monkeypatch):
     sc = pt.Scene(scene_path("cornell_box_with_volume"), 64, 36)
     assert pt.spec_build_check(sc, 4) > 20000
     assert _table_survives(out)
+
+
+def _leaf_slots(text):
+    rows = re.findall(r"^  \{([-0-9, ]+)\},$", text, re.M)
+    return [(int(r.split(",")[0]), int(r.split(",")[1]), int(r.split(",")[2])) for r in rows]   # (kind, instance, slot)
+
+
+def test_the_rects_that_wall_a_scene_in_are_marked():
+    # DOp::slot bit 5 (pt_context.cpp rect_walls_scene): the per-scene k_connect proves these unreachable for a shadow ray instead of
+    # testing them.  The Cornell boxes: floor, ceiling (one unit above the light), back and side walls -- never the light
+    import json
+    from scene_gen import room_scene
+
+    # -- and of a box its sides (bits 8-13, box::hit's order): the bottoms (XZ at p0.y, bit 12) of the blocks that stand on the floor
+    for scene, walls, boxes in (("cornell_box", 5, 2), ("cornell_box_with_volume", 5, 1), ("cornell_box_small_lights", 6, 2)):
+        text = pt.spec_header(pt.Scene(scene_path(scene), 64, 36))
+        assert int(re.search(r"#define PT_SPEC_NWALL (\d+)", text).group(1)) == walls + boxes
+        assert sum(1 for k, _, s in _leaf_slots(text) if 2 <= k <= 4 and (s & 48) == 32) == walls
+        assert [s >> 8 for k, _, s in _leaf_slots(text) if k == 5] == [16] * boxes
+    # generated rooms: a partition inside the room and the lights are never marked; a ceiling whose light hangs closer than 2^-10 of
+    # the room under it is not either (the kernel's per-ray proof would fail for the far corners), every other wall is
+    marked = unmarked_ceilings = 0
+    for seed in range(24):
+        js = room_scene(seed)
+        text = pt.spec_header(pt.Scene(text=json.dumps(js), width=48, height=36))
+        inst = js["instances"]
+        H = max(i["transform"]["translate"][1] for i in inst if i["type"] == "ref" and i["primitive"]["id"] == "floor")
+        gap = min(H - i["transform"]["translate"][1] for i in inst if i["type"] == "direct" and i["primitive"].get("material", {}).get("id") == "light")
+        for kind, ii, slot in _leaf_slots(text):
+            if not 2 <= kind <= 4:
+                continue
+            e, wall = inst[ii], (slot & 48) == 32
+            mat = e["primitive"].get("material", {}).get("id") if e["type"] == "direct" else None
+            is_partition = e["type"] == "direct" and mat == "white" and e["primitive"].get("align") == "yz"
+            is_ceiling = e["type"] == "ref" and e["primitive"]["id"] == "floor" and e["transform"]["translate"][1] > 0
+            if mat == "light" or is_partition:
+                assert not wall, (seed, ii)
+            elif is_ceiling and gap < 0.25:
+                assert not wall, (seed, ii, gap)
+                unmarked_ceilings += 1
+            elif not is_ceiling or gap >= 1.0:
+                assert wall, (seed, ii, gap)
+            marked += wall
+    assert marked > 100 and unmarked_ceilings > 0

@@ -6,7 +6,7 @@
 For every seed: a generated scene (tests/scene_gen.py; varying instance counts so that both the flat program and the tree
 program of the fast sweep run, plus the general sweep with PATHTRACE_HIP_TRAVERSAL=general on every 5th seed; light_samples
 4, 1, 2, 7, 3 by seed so that k_shade's staged and unstaged instantiations both run; the chunk sort forced on for every 3rd
-seed and the staging forced off for every 7th, a medium inside a medium on every 9th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
+seed and the staging forced off for every 7th, a medium inside a medium on every 9th, a walled room of rects on every 4th), rendered at 96x64x4 on the GPU and by the oracle in stream mode; framebuffer
 bits and all nine path counters must agree.  With PATHTRACE_HIP_SPEC=sync in the environment every scene is rendered by its own
 build of the traversal kernels (counted as "per_scene_build")."""
 import json
@@ -21,7 +21,7 @@ import numpy as np
 
 import pathtrace_amd as pt
 from oracle import pt_oracle as oracle
-from scene_gen import random_scene
+from scene_gen import random_scene, room_scene
 
 CTR = {"rays": "rays", "extension_rays": "ext_rays", "extension_hits": "ext_hits", "shadow_rays": "shadow_rays",
        "term_miss": "term_miss", "term_rr": "term_rr", "term_emitter": "term_emitter", "term_pdf": "term_pdf",
@@ -37,6 +37,10 @@ def main():
         n_inst = [None, 6, 12, 30, 60, 120][seed % 6]
         nested = seed % 9 == 0   # a medium whose boundary is a medium (round 5): the general sweep carries the whole scene
         js = random_scene(seed, nested=nested) if n_inst is None else random_scene(seed, n_inst=n_inst, volume=(seed % 4 != 0), nested=nested)
+        room = seed % 4 == 3     # a closed room of rects (round 5): the walls the module's shadow sweep proves unreachable
+        if room:
+            js = room_scene(seed)
+            modes["walled_room"] = modes.get("walled_room", 0) + 1
         general = seed % 5 == 0
         if general:
             os.environ["PATHTRACE_HIP_TRAVERSAL"] = "general"
