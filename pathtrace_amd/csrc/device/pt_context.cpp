@@ -232,6 +232,9 @@ static bool plane_walls_scene(const pt_scene_desc *sc, int ii, int axis, double 
     for (int l = 0; l < sc->n_lights; l++) {
         const int li = sc->lights[l];
         if (li < 0 || li >= sc->n_instances || li == ii) return false;
+        // the sample sits at t = 1 for a rect light only (rect::random returns point - origin, primitive.h:168-175); a sphere light
+        // is sampled by direction (its hit lies at t = distance: every ray would go to the general sweep), other shapes not at all
+        if (sc->primitives[sc->instances[li].primitive].type != PT_PRIM_RECT) return false;
         for (int c = 0; c < 8; c++) {
             const double v = local(sc->instances[li].bbox, c);
             if (!(std::fabs(v) > 0.0) || !std::isfinite(v)) return false;

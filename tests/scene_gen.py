@@ -136,6 +136,9 @@ def room_scene(seed: int):
         lw, ld = u(40, W / 3), u(40, D / 3)
         inst.append({"type": "direct", "primitive": {"type": "rect", "material": {"id": "light"}, "size": [lw, ld]},
                      "transform": {"translate": [u(lw, W - lw), H - gap, u(ld, D - ld)]}})
+    if rng.integers(0, 6) == 0:   # a sphere light is sampled by direction, its hit is not at t = 1: no wall may be marked then
+        inst.append({"type": "direct", "primitive": {"type": "sphere", "material": {"id": "light"}, "radius": u(10, 30)},
+                     "transform": {"translate": [u(W / 4, 3 * W / 4), u(H / 2, 3 * H / 4), u(D / 4, 3 * D / 4)]}})
     for k in range(int(rng.integers(1, 3))):
         s = [u(40, W / 4), u(40, H / 2), u(40, D / 4)]
         hd = 0.5 * float(np.hypot(s[0], s[2])) + 2.0   # the block turns about y inside the room, whatever the angle

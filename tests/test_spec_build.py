@@ -184,13 +184,18 @@ def test_the_rects_that_wall_a_scene_in_are_marked():
         assert [s >> 8 for k, _, s in _leaf_slots(text) if k == 5] == [16] * boxes
     # generated rooms: a partition inside the room and the lights are never marked; a ceiling whose light hangs closer than 2^-10 of
     # the room under it is not either (the kernel's per-ray proof would fail for the far corners), every other wall is
-    marked = unmarked_ceilings = 0
+    marked = unmarked_ceilings = spheres = 0
     for seed in range(24):
         js = room_scene(seed)
         text = pt.spec_header(pt.Scene(text=json.dumps(js), width=48, height=36))
         inst = js["instances"]
         H = max(i["transform"]["translate"][1] for i in inst if i["type"] == "ref" and i["primitive"]["id"] == "floor")
-        gap = min(H - i["transform"]["translate"][1] for i in inst if i["type"] == "direct" and i["primitive"].get("material", {}).get("id") == "light")
+        gap = min(H - i["transform"]["translate"][1] for i in inst if i["type"] == "direct" and i["primitive"].get("material", {}).get("id") == "light"
+                  and i["primitive"]["type"] == "rect")
+        if any(i["type"] == "direct" and i["primitive"]["type"] == "sphere" for i in inst):   # a light that is not sampled by point: nothing marked
+            assert not any((s & 48) == 32 or (k == 5 and s >> 8) for k, _, s in _leaf_slots(text)), seed
+            spheres += 1
+            continue
         for kind, ii, slot in _leaf_slots(text):
             if not 2 <= kind <= 4:
                 continue
@@ -206,4 +211,4 @@ def test_the_rects_that_wall_a_scene_in_are_marked():
             elif not is_ceiling or gap >= 1.0:
                 assert wall, (seed, ii, gap)
             marked += wall
-    assert marked > 100 and unmarked_ceilings > 0
+    assert marked > 80 and unmarked_ceilings > 0 and spheres > 0
