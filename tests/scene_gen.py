@@ -103,7 +103,7 @@ def random_scene(seed: int, n_inst=None, volume=None, textures=None, nested=Fals
     return {"camera": cam, "world": world, "assets": [], "textures": tex, "materials": mats, "primitives": prims, "instances": inst}
 
 
-def room_scene(seed: int):
+def room_scene(seed: int, clutter: int = 0):
     """A closed room of rects (translated, and rotated by half and three-half turns like the reference's Cornell box builds its
     ceiling and back wall) with one or two rect lights hung close under the ceiling, a block or two, sometimes a fog block and a
     free-standing partition: the scenes whose walls the shadow sweep of the per-scene build proves unreachable instead of testing
@@ -144,6 +144,10 @@ def room_scene(seed: int):
         hd = 0.5 * float(np.hypot(s[0], s[2])) + 2.0   # the block turns about y inside the room, whatever the angle
         inst.append({"type": "direct", "primitive": {"type": "box", "material": {"id": str(rng.choice(["white", "metal"]))}, "size": s},
                      "transform": {"translate": [u(hd, W - hd), s[1] / 2, u(hd, D - hd)], "rotate": [0.0, u(-0.3, 0.3), 0.0]}})
+    for k in range(clutter):   # many small blocks on the floor: more than 24 instances, the fast program keeps its tree (drawn only when asked for)
+        s = [u(8, 30), u(8, 60), u(8, 30)]
+        inst.append({"type": "direct", "primitive": {"type": "box", "material": {"id": str(rng.choice(["white", "metal", "red"]))}, "size": s},
+                     "transform": {"translate": [u(40, W - 40), s[1] / 2, u(40, D - 40)]}})
     if rng.integers(0, 3) == 0:
         prims.append({"id": "vbox", "type": "box", "size": [u(60, W / 3), u(60, H / 2), u(60, D / 3)]})
         prims.append({"id": "fog", "type": "volume", "primitive": "vbox", "density": u(0.002, 0.02), "color": col(0.5, 1.0)})

@@ -125,7 +125,7 @@ def test_walled_rooms_match_the_oracle_on_the_module(oracle, light_samples, monk
     from test_gpu_fuzz import CTR
 
     for seed in range(10):
-        js = room_scene(seed)
+        js = room_scene(seed, clutter=30 if seed >= 8 else 0)   # the last two: 40 instances, the fast program keeps its tree of boxes
         sc = pt.Scene(text=json.dumps(js), width=56, height=40)
         osc = oracle.Scene(oracle.sp.load_scene_params(js))
         o, oc = osc.render_stream(oracle.make_config(56, 40, 3, light_samples=light_samples), seed=seed, threads=2)
