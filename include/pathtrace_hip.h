@@ -258,9 +258,10 @@ int pt_set_stream(pt_ctx *ctx, void *hip_stream);
 /* Batches rotate over n of the context's stream lanes (default: all it owns, 3).  n = 1 runs the kernels of consecutive
  * batches one after the other: per-kernel measurements.  Returns the number of lanes the context owns, < 0 on error. */
 int pt_set_lanes(pt_ctx *ctx, int32_t n);
-/* Planner of a tile-partitioned render: rays_out[k] = World::hit queries the device performs (pt_counters::rays_traced:
- * what a tile costs) for `spp` samples per pixel of rect k, for all rects in one pass (replaces one render + counter
- * read per tile).  Framebuffer and counters are cleared before and after. */
+/* Planner of a tile-partitioned render: rays_out[k] = the reference's ray count (pt_counters::rays: extension rays +
+ * light_samples shadow rays per hit -- what a tile's time follows; up to ABI v6's first form: rays_traced) for `spp` samples
+ * per pixel of rect k, for all rects in one pass (replaces one render + counter read per tile).  Framebuffer and counters
+ * are cleared before and after. */
 int pt_measure_tile_costs(pt_ctx *ctx, int32_t n_rects, const int32_t *rects, int32_t spp, uint64_t *rays_out);
 /* The per-scene build of the traversal sweep: the scene's traversal program as a header text for pt_kernels.hip
  * (PT_SPEC_HEADER).  Host only (no device needed).  Returns the text length; buf receives it when cap > length.

@@ -1474,8 +1474,9 @@ extern "C" int pt_prime(pt_ctx *c, int32_t n_rects, const int32_t *rects, int32_
     }
     return pt_clear_framebuffer(c);
 }
-// The planner of a tile-partitioned render: World::hit queries PERFORMED (extension rays + the shadow rays
-// of hits that got a shadow record: pt_counters::rays_traced) for `spp` samples per pixel of every rect, counted per rect
+// The planner of a tile-partitioned render: the reference's ray count (pt_counters::rays: extension rays +
+// light_samples shadow rays per hit, integrator.h:192, 246-247 -- what a tile's time follows, pt_kernels.hip k_tally) for `spp`
+// samples per pixel of every rect, counted per rect
 // in ONE pass over all of them -- the rects are rendered together as ordinary wavefront batches and k_tally attributes
 // every bounce's rays to the rect the path's pixel lies in.  Leaves framebuffer and counters cleared.  Deterministic: the
 // RNG is keyed by pixel and sample.

@@ -3070,11 +3070,15 @@ DEVI int tile_of_slot(const DBatch &b, int slot)
 }
 __global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int qi, int bounce, int light_samples, unsigned long long *__restrict__ cost)
 {
+    // What a tile costs, in the reference's own unit (pt_counters::rays, integrator.h:192, 246-247): one extension ray per path this
+    // bounce extended and light_samples shadow rays per HIT -- also for the hits whose samples cannot contribute, which get no shadow
+    // record here (their rays are counted, not traced): a tile's time follows its hits (k_shade works on every one of them), not
+    // the records that survive.  Measured (round 5, eight ranks' tile lists on one GPU): rank time against this count +-0.1 ms of
+    // 16, against the traced rays +-0.3.  Runs behind k_shade, in front of k_connect: st.hit holds this bounce's hit ids.
     const DQueue q = st.q[qi];
     const int cps = b.seg_cap / PT_BLOCK, total_chunks = b.n_seg * cps;
-    // the kernels' own bounds (chunk_limit): no segment of the path queue holds more than live_p entries, none of the shadow
-    // queue more than live_s -- a count word beyond them is not trusted (k_extend zeroes the words of every bounce, also of a
-    // batch whose paths have all died; the bound keeps this walk short as well)
+    // the kernels' own bound (chunk_limit): no segment of the path queue holds more than live_p entries -- a count word beyond it
+    // is not trusted (k_extend zeroes the words of every bounce, also of a batch whose paths have all died)
     const int live_p = (PT_FUSE_GENERATE && bounce == 0) ? cps : chunk_limit(st.qmax, 0, bounce - 1, 1, cps);
     for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {           // the paths this bounce extended
         const int seg = c / cps, i = (c - seg * cps) * PT_BLOCK + (int)threadIdx.x;
@@ -3082,16 +3086,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_tally(DStreams st, DBatch b, int q
         if (i >= ((PT_FUSE_GENERATE && bounce == 0) ? seg_live<true>(q, b, seg) : seg_live<false>(q, b, seg))) continue;
         const long long pos = (long long)seg * b.seg_cap + i;
         const int slot = (PT_FUSE_GENERATE && bounce == 0) ? (int)pos : __float_as_int(q.r0[pos].w);
-        atomicAdd(cost + tile_of_slot(b, slot), 1ull);
-    }
-    const int cps_o = b.seg_cap_out / PT_BLOCK, total_o = b.n_seg_out * cps_o;
-    const int live_s = chunk_limit(st.qmax, 1, bounce, 1, cps_o);
-    for (int c = blockIdx.x; c < total_o; c += gridDim.x) {                // the shadow records this bounce wrote
-        const int seg = c / cps_o, i = (c - seg * cps_o) * PT_BLOCK + (int)threadIdx.x;
-        if (c - seg * cps_o >= live_s) continue;
-        if (i >= st.sq.count[seg]) continue;
-        const int slot = __float_as_int(st.sq.p0[(long long)seg * b.seg_cap_out + i].w) & 0x7fffffff;
-        atomicAdd(cost + tile_of_slot(b, slot), (unsigned long long)light_samples);
+        const bool hit = __float_as_int(st.hit[pos].y) >= 0;
+        atomicAdd(cost + tile_of_slot(b, slot), hit ? 1ull + (unsigned long long)light_samples : 1ull);
     }
 }
 void launch_tally(const DScene &S, const DStreams &st, const DBatch &b, int qi, int bounce, unsigned long long *cost, hipStream_t s)

@@ -66,8 +66,8 @@ def tiles_for_rank(width: int, height: int, block_w: int, block_h: int, rank: in
 
 
 def measure_tile_costs(renderer, tiles) -> List[int]:
-    """Work per tile in ray-equivalents: World::hit queries performed for one sample per pixel (extension rays + the shadow
-    rays of the hits that get a shadow record) plus one unit per camera sample (ray generation + framebuffer accumulation).  `renderer` is a pathtrace_amd.Renderer; its framebuffer and counters are
+    """Work per tile in ray-equivalents: the reference's ray count for one sample per pixel (extension rays + light_samples shadow
+    rays per hit, traced or not: a tile's time follows its hits) plus one unit per camera sample (ray generation + framebuffer accumulation).  `renderer` is a pathtrace_amd.Renderer; its framebuffer and counters are
     cleared afterwards.  Deterministic (the RNG is keyed by pixel and sample), so all ranks agree.  One pass over all
     tiles (pt_measure_tile_costs: a tally kernel attributes every bounce's rays to the tile of the path's pixel), not
     one render and one blocking counter read per tile."""

@@ -198,7 +198,7 @@ def test_cost_balanced_tile_ownership(oracle):
     tiles = pt.spiral_tiles(w, h, tile, tile)
     costs = measure_tile_costs(r, tiles)
     assert r.counters()["rays"] == 0 and not r.framebuffer().any()      # measuring leaves no trace
-    # a tile's cost = the rays the device traces for it (one sample per pixel) + one unit per pixel: the tile rendered alone
+    # a tile's cost = the reference's ray count for it (one sample per pixel) + one unit per pixel: the tile rendered alone
     # says the same, and the extension rays among them are the oracle's
     osc = oracle.Scene.from_json(scene_path(scene))
     cfg = oracle_cfg(oracle, w, h, 1)
@@ -209,7 +209,7 @@ def test_cost_balanced_tile_ownership(oracle):
         ck = r.counters()
         _, oc = osc.render_stream(cfg, seed=0, rect=tiles[k], threads=2, fb=scratch)
         assert ck["rays"] == oc["rays"] and ck["extension_rays"] == oc["ext_rays"]
-        assert costs[k] == ck["rays_traced"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1])
+        assert costs[k] == ck["rays"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1])
     r.clear()
     # the same counts when the slot budget cuts the tiles into bands and the pass into several batch groups, and for 2 spp
     r_small = pt.Renderer(sc, max_paths_in_flight=5000)
@@ -217,7 +217,7 @@ def test_cost_balanced_tile_ownership(oracle):
     two = r_small.measure_tile_costs(tiles[:5], 2)
     r_small.close()
     r.render_tiles_async([tiles[1]], 0, 2)
-    assert two[1] == r.counters()["rays_traced"]
+    assert two[1] == r.counters()["rays"]
     r.clear()
     per_rank = [tiles_for_rank(w, h, tile, tile, k, world, costs) for k in range(world)]
     assert sorted(t for tr in per_rank for t in tr) == sorted(tiles)
@@ -272,8 +272,8 @@ def test_production_queue_geometry_in_one_batch(oracle, spec, monkeypatch):
 
 
 @pytest.mark.parametrize("scene,max_bounces", [("three_orbs", 50), ("light_test", 12), ("cornell_box", 50)])
-def test_tile_costs_equal_traced_rays_when_batches_die_early(scene, max_bounces):
-    # pt_measure_tile_costs' contract: a tile's cost = the rays the device traces for it + one per pixel.  Open scenes and
+def test_tile_costs_equal_the_ray_count_when_batches_die_early(scene, max_bounces):
+    # pt_measure_tile_costs' contract: a tile's cost = the reference's ray count for it + one per pixel.  Open scenes and
     # small batches die many bounces before max_bounces: the tally of the remaining bounces must add nothing.
     from pathtrace_amd.distributed import measure_tile_costs
 
@@ -286,10 +286,10 @@ def test_tile_costs_equal_traced_rays_when_batches_die_early(scene, max_bounces)
         for k in (0, len(tiles) // 3, len(tiles) - 1):
             r.clear()
             r.render_tiles_async([tiles[k]], 0, 1)
-            assert costs[k] == r.counters()["rays_traced"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1]), (scene, max_paths, k)
+            assert costs[k] == r.counters()["rays"] + (tiles[k][2] - tiles[k][0]) * (tiles[k][3] - tiles[k][1]), (scene, max_paths, k)
         r.clear()
         r.render_tiles_async(tiles, 0, 1)
-        assert sum(costs) == r.counters()["rays_traced"] + w * h
+        assert sum(costs) == r.counters()["rays"] + w * h
         r.close()
 
 
